@@ -1,0 +1,706 @@
+/*
+ * ip_oracle.c -- CPU restatement of rocket-path's F3/F4 interior-point step.
+ * TEST INFRASTRUCTURE ONLY -- see ip_oracle.h for scope, citations and the parity pin.
+ *
+ * Every function names the reference lines it follows.  Operation order is the
+ * reference's; compile with -ffp-contract=off so no multiply-add is fused.
+ */
+#include "ip_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ACCEL_LIMIT 100.0 /* onedpath_ip.cpp:54, onedpath2_ip.cpp:57 */
+#define NV 3              /* numVars, onedpath_ip.cpp:45 */
+#define MAXC 8
+#define MAXN (NV + MAXC)
+
+static double sqr(double x) { return x * x; }       /* onedpath_ip.cpp:159-162 */
+static double cube(double x) { return x * x * x; }  /* onedpath_ip.cpp:164-167 */
+
+/* ------------------------------------------------------------------ */
+/* onedpath_ip.cpp:372-392 (same text at onedpath2_ip.cpp:332-352)     */
+void orc_accel_init(double x0, double v0, double x1, double v1, double t,
+                    double *a, double *dAdT, double *dAdV0, double *dAdV1)
+{
+    const double dX = x1 - x0;
+    *a = (dX * 6.0 / t + v0 * -4.0 + v1 * -2.0) / t;
+    *dAdT = (dX * -12.0 / t + v0 * 4.0 + v1 * 2.0) / sqr(t);
+    *dAdV0 = -4.0 / t;
+    *dAdV1 = -2.0 / t;
+}
+
+/* onedpath_ip.cpp:394-411 */
+void orc_accel_init_2nd(double x0, double v0, double x1, double v1, double t,
+                        double *sTT, double *sTV0, double *sTV1)
+{
+    const double dX = x1 - x0;
+    *sTT = (dX * 36.0 / t - v0 * 8.0 - v1 * 4.0) / cube(t);
+    *sTV0 = 4 / sqr(t);
+    *sTV1 = 2 / sqr(t);
+}
+
+/* onedpath_ip.cpp:413-433 */
+void orc_accel_final(double x0, double v0, double x1, double v1, double t,
+                     double *a, double *dAdT, double *dAdV0, double *dAdV1)
+{
+    const double dX = x1 - x0;
+    *a = (dX * -6.0 / t + v0 * 2.0 + v1 * 4.0) / t;
+    *dAdT = (dX * 12.0 / t + v0 * -2.0 + v1 * -4.0) / sqr(t);
+    *dAdV0 = 2.0 / t;
+    *dAdV1 = 4.0 / t;
+}
+
+/* onedpath_ip.cpp:435-452 */
+void orc_accel_final_2nd(double x0, double v0, double x1, double v1, double t,
+                         double *sTT, double *sTV0, double *sTV1)
+{
+    const double dX = x1 - x0;
+    *sTT = (dX * -36.0 / t + v0 * 4.0 + v1 * 8.0) / cube(t);
+    *sTV0 = -2.0 / sqr(t);
+    *sTV1 = -4.0 / sqr(t);
+}
+
+/* ------------------------------------------------------------------ */
+int orc_num_constraints(int variant) { return variant == ORC_VARIANT_F4 ? 4 : 8; }
+int orc_state_len(int variant) { return variant == ORC_VARIANT_F4 ? ORC4_M : ORC3_M; }
+
+/* Where the five constants sit: right after the multipliers in both enums. */
+typedef struct { double pos0, vel0, pos1, pos2, vel2; } seg_consts;
+
+static seg_consts get_consts(int variant, const double *var)
+{
+    const int base = NV + orc_num_constraints(variant);
+    seg_consts k;
+    k.pos0 = var[base + 0];
+    k.vel0 = var[base + 1];
+    k.pos1 = var[base + 2];
+    k.pos2 = var[base + 3];
+    k.vel2 = var[base + 4];
+    return k;
+}
+
+/* Segment end selected by a constraint: seg 0/1, end 0 = initial / 1 = final. */
+static void accel_at(int seg, int end, const double *var, const seg_consts *k,
+                     double *a, double *dAdT, double *dAdV0, double *dAdV1)
+{
+    if (seg == 0) {
+        if (end == 0) orc_accel_init(k->pos0, k->vel0, k->pos1, var[ORC3_VEL1], var[ORC3_DUR0], a, dAdT, dAdV0, dAdV1);
+        else          orc_accel_final(k->pos0, k->vel0, k->pos1, var[ORC3_VEL1], var[ORC3_DUR0], a, dAdT, dAdV0, dAdV1);
+    } else {
+        if (end == 0) orc_accel_init(k->pos1, var[ORC3_VEL1], k->pos2, k->vel2, var[ORC3_DUR1], a, dAdT, dAdV0, dAdV1);
+        else          orc_accel_final(k->pos1, var[ORC3_VEL1], k->pos2, k->vel2, var[ORC3_DUR1], a, dAdT, dAdV0, dAdV1);
+    }
+}
+
+static void accel2_at(int seg, int end, const double *var, const seg_consts *k,
+                      double *sTT, double *sTV0, double *sTV1)
+{
+    if (seg == 0) {
+        if (end == 0) orc_accel_init_2nd(k->pos0, k->vel0, k->pos1, var[ORC3_VEL1], var[ORC3_DUR0], sTT, sTV0, sTV1);
+        else          orc_accel_final_2nd(k->pos0, k->vel0, k->pos1, var[ORC3_VEL1], var[ORC3_DUR0], sTT, sTV0, sTV1);
+    } else {
+        if (end == 0) orc_accel_init_2nd(k->pos1, var[ORC3_VEL1], k->pos2, k->vel2, var[ORC3_DUR1], sTT, sTV0, sTV1);
+        else          orc_accel_final_2nd(k->pos1, var[ORC3_VEL1], k->pos2, k->vel2, var[ORC3_DUR1], sTT, sTV0, sTV1);
+    }
+}
+
+/* F3: evalConstraint0..7, onedpath_ip.cpp:454-464, 477-487, 500-510, 523-533, 546-556,
+ *     569-579, 592-602, 615-625.   i -> (segment i/4, end (i/2)%2, sign: even = minus).
+ * F4: evalConstraint0..3, onedpath2_ip.cpp:414-424, 451-461, 476-486, 501-511.
+ *     i -> (segment i/2, end i%2). */
+void orc_constraint(int variant, int i, const double *var, double *err, double grad[3])
+{
+    const seg_consts k = get_consts(variant, var);
+    double a, dAdT, dAdV0, dAdV1;
+    if (variant == ORC_VARIANT_F4) {
+        const int seg = i / 2, end = i % 2;
+        accel_at(seg, end, var, &k, &a, &dAdT, &dAdV0, &dAdV1);
+        *err = (sqr(a) - sqr(ACCEL_LIMIT)) / 2.0;
+        if (seg == 0) {
+            grad[ORC3_DUR0] = a * dAdT;
+            grad[ORC3_DUR1] = 0;
+            grad[ORC3_VEL1] = a * dAdV1;
+        } else {
+            grad[ORC3_DUR0] = 0;
+            grad[ORC3_DUR1] = a * dAdT;
+            grad[ORC3_VEL1] = a * dAdV0;
+        }
+        return;
+    }
+    {
+        const int seg = i / 4, end = (i / 2) % 2, plus = i % 2;
+        accel_at(seg, end, var, &k, &a, &dAdT, &dAdV0, &dAdV1);
+        if (!plus) {
+            *err = -a - ACCEL_LIMIT;
+            if (seg == 0) { grad[ORC3_DUR0] = -dAdT; grad[ORC3_DUR1] = 0; grad[ORC3_VEL1] = -dAdV1; }
+            else          { grad[ORC3_DUR0] = 0; grad[ORC3_DUR1] = -dAdT; grad[ORC3_VEL1] = -dAdV0; }
+        } else {
+            *err = a - ACCEL_LIMIT;
+            if (seg == 0) { grad[ORC3_DUR0] = dAdT; grad[ORC3_DUR1] = 0; grad[ORC3_VEL1] = dAdV1; }
+            else          { grad[ORC3_DUR0] = 0; grad[ORC3_DUR1] = dAdT; grad[ORC3_VEL1] = dAdV0; }
+        }
+    }
+}
+
+/* F3: evalConstraintSecondDeriv0..7, onedpath_ip.cpp:466-475 ... 627-636.
+ * F4: evalConstraintSecondDeriv0..3, onedpath2_ip.cpp:426-449, 463-474, 488-499, 513-524;
+ *     the (vel1X,vel1X) entry is never written there and stays 0 -- reproduced. */
+void orc_constraint_hess(int variant, int i, const double *var, double H[9])
+{
+    const seg_consts k = get_consts(variant, var);
+    double sTT, sTV0, sTV1;
+    int j;
+    for (j = 0; j < 9; ++j) H[j] = 0.0;
+    if (variant == ORC_VARIANT_F4) {
+        const int seg = i / 2, end = i % 2;
+        double a, dAdT, dAdV0, dAdV1;
+        accel_at(seg, end, var, &k, &a, &dAdT, &dAdV0, &dAdV1);
+        accel2_at(seg, end, var, &k, &sTT, &sTV0, &sTV1);
+        if (seg == 0) {
+            H[ORC3_DUR0 * 3 + ORC3_DUR0] = sqr(dAdT) + a * sTT;
+            H[ORC3_DUR0 * 3 + ORC3_VEL1] = H[ORC3_VEL1 * 3 + ORC3_DUR0] = dAdT * dAdV1 + a * sTV1;
+        } else {
+            H[ORC3_DUR1 * 3 + ORC3_DUR1] = sqr(dAdT) + a * sTT;
+            H[ORC3_DUR1 * 3 + ORC3_VEL1] = H[ORC3_VEL1 * 3 + ORC3_DUR1] = dAdT * dAdV0 + a * sTV0;
+        }
+        return;
+    }
+    {
+        const int seg = i / 4, end = (i / 2) % 2, plus = i % 2;
+        accel2_at(seg, end, var, &k, &sTT, &sTV0, &sTV1);
+        if (seg == 0) {
+            H[ORC3_DUR0 * 3 + ORC3_DUR0] = plus ? sTT : -sTT;
+            H[ORC3_DUR0 * 3 + ORC3_VEL1] = plus ? sTV1 : -sTV1;
+            H[ORC3_VEL1 * 3 + ORC3_DUR0] = plus ? sTV1 : -sTV1;
+        } else {
+            H[ORC3_DUR1 * 3 + ORC3_DUR1] = plus ? sTT : -sTT;
+            H[ORC3_DUR1 * 3 + ORC3_VEL1] = plus ? sTV0 : -sTV0;
+            H[ORC3_VEL1 * 3 + ORC3_DUR1] = plus ? sTV0 : -sTV0;
+        }
+    }
+}
+
+/* onedpath_ip.cpp:794-808 */
+double orc_gap(int variant, const double *var)
+{
+    const int m = orc_num_constraints(variant);
+    double mu = 0;
+    int i;
+    for (i = 0; i < m; ++i) {
+        double err, grad[3];
+        orc_constraint(variant, i, var, &err, grad);
+        mu -= err * var[ORC3_LAM0 + i];
+    }
+    return mu;
+}
+
+/* onedpath_ip.cpp:753-783 */
+void orc_residual(int variant, const double *var, double perturbation, double *r)
+{
+    const int m = orc_num_constraints(variant);
+    int i, j;
+    for (i = 0; i < NV + m; ++i) r[i] = 0.0;
+    r[ORC3_DUR0] = 1;
+    r[ORC3_DUR1] = 1;
+    for (i = 0; i < m; ++i) {
+        const double scale = var[ORC3_LAM0 + i];
+        double err, grad[3];
+        orc_constraint(variant, i, var, &err, grad);
+        for (j = 0; j < NV; ++j) r[j] += scale * grad[j];
+        r[NV + i] = scale * err + perturbation;
+    }
+}
+
+/* Matrix<double,N,1>::squaredNorm() as Eigen 3.3.0 evaluates it with SSE2 packets of two
+ * doubles (libs/eigen/Eigen/src/Core/Redux.h: redux_vec_unroller halves the packet range
+ * recursively, then predux adds the two lanes, then the odd tail element is added). */
+static double packet_tree(const double *sq, int start, int len, int lane)
+{
+    if (len == 1) return sq[2 * start + lane];
+    {
+        const int half = len / 2;
+        return packet_tree(sq, start, half, lane) + packet_tree(sq, start + half, len - half, lane);
+    }
+}
+
+static double eigen_squared_norm(const double *v, int n)
+{
+    double sq[MAXN + 1];
+    const int npk = n / 2;
+    int i;
+    double res;
+    for (i = 0; i < n; ++i) sq[i] = v[i] * v[i];
+    if (npk == 0) return n ? sq[0] : 0.0;
+    res = packet_tree(sq, 0, npk, 0) + packet_tree(sq, 0, npk, 1);
+    for (i = 2 * npk; i < n; ++i) res = res + sq[i];
+    return res;
+}
+
+/* onedpath_ip.cpp:785-792 */
+double orc_residual_norm(int variant, const double *var, double perturbation)
+{
+    double r[MAXN];
+    orc_residual(variant, var, perturbation, r);
+    return eigen_squared_norm(r, NV + orc_num_constraints(variant));
+}
+
+/* onedpath_ip.cpp:738-751 */
+int orc_constraints_satisfied(int variant, const double *var)
+{
+    const int m = orc_num_constraints(variant);
+    int i;
+    for (i = 0; i < m; ++i) {
+        double err, grad[3];
+        orc_constraint(variant, i, var, &err, grad);
+        if (err > 0.0) return 0;
+    }
+    return 1;
+}
+
+/* onedpath_ip.cpp:723-736 */
+static void trajectory_step(int variant, const double *orig, const double *dir, double scale, double *out)
+{
+    const int m = orc_num_constraints(variant);
+    const int c = NV + m, M = orc_state_len(variant);
+    int i;
+    for (i = 0; i < c; ++i) out[i] = orig[i] + dir[i] * scale;
+    for (i = c; i < M; ++i) out[i] = orig[i];
+}
+
+/* onedpath_ip.cpp:812-861: the perturbation, the (3+m)x(3+m) matrix and the residual. */
+void orc_kkt(int variant, const double *var, double *mat, double *r, double *perturbation)
+{
+    const int m = orc_num_constraints(variant);
+    const int c = NV + m;
+    int i, j, row, col;
+    const double p = orc_gap(variant, var) / (m * 10.0);
+#define MAT(rr, cc) mat[(size_t)(cc) * c + (rr)]
+    for (i = 0; i < c * c; ++i) mat[i] = 0.0;
+    for (i = 0; i < c; ++i) r[i] = 0.0;
+    r[ORC3_DUR0] = 1;
+    r[ORC3_DUR1] = 1;
+    for (i = 0; i < m; ++i) {
+        const double scale = var[ORC3_LAM0 + i];
+        double err, grad[3], H[9];
+        orc_constraint(variant, i, var, &err, grad);
+        orc_constraint_hess(variant, i, var, H);
+        for (row = 0; row < NV; ++row)
+            for (col = 0; col < NV; ++col)
+                MAT(row, col) += H[row * 3 + col] * scale;
+        for (j = 0; j < NV; ++j) {
+            MAT(j, NV + i) = grad[j];
+            MAT(NV + i, j) = scale * grad[j];
+            r[j] += scale * grad[j];
+        }
+        MAT(NV + i, NV + i) = err;
+        r[NV + i] = scale * err + p;
+    }
+#undef MAT
+    *perturbation = p;
+}
+
+/* ------------------------------------------------------------------ */
+/* ColPivHouseholderQR<Matrix>::computeInPlace + _solve_impl,
+ * libs/eigen/Eigen/src/QR/ColPivHouseholderQR.h:480-611, with makeHouseholder /
+ * applyHouseholderOnTheLeft of libs/eigen/Eigen/src/Householder/Householder.h:65-131.
+ * Returns nonzero_pivots.  Square systems only (all the path needs). */
+static double vec_norm(const double *v, int n)
+{
+    /* stableless norm(): sqrt(squaredNorm()) */
+    return sqrt(eigen_squared_norm(v, n));
+}
+
+int orc_colpiv_qr_solve(int n, const double *A, const double *b, double *x)
+{
+    double qr[16 * 16], hco[16], nrm_upd[16], nrm_dir[16], tmp[16], c[16];
+    int transp[16], perm[16];
+    int k, i, j, nonzero_pivots;
+    double threshold_helper, maxnorm, maxpivot;
+    const double eps = DBL_EPSILON;
+    const double downdate_thr = sqrt(eps);
+#define QR(rr, cc) qr[(size_t)(cc) * n + (rr)]
+    if (n < 1 || n > 16) return -1;
+    memcpy(qr, A, sizeof(double) * (size_t)n * n);
+
+    for (k = 0; k < n; ++k) {                                       /* :502-507 */
+        nrm_dir[k] = vec_norm(&QR(0, k), n);
+        nrm_upd[k] = nrm_dir[k];
+    }
+    maxnorm = nrm_upd[0];
+    for (k = 1; k < n; ++k) if (nrm_upd[k] > maxnorm) maxnorm = nrm_upd[k];
+    threshold_helper = (maxnorm * eps) * (maxnorm * eps) / (double)n; /* :509 */
+    nonzero_pivots = n;                                              /* :512 */
+    maxpivot = 0;
+
+    for (k = 0; k < n; ++k) {                                        /* :515 */
+        int big = k;
+        double bigv = nrm_upd[k], big_sq, beta, tau, tail_sq, c0;
+        for (j = k + 1; j < n; ++j) if (nrm_upd[j] > bigv) { bigv = nrm_upd[j]; big = j; }
+        big_sq = bigv * bigv;                                        /* :519 */
+        if (nonzero_pivots == n && big_sq < threshold_helper * (double)(n - k)) /* :524 */
+            nonzero_pivots = k;
+        transp[k] = big;                                             /* :528 */
+        if (k != big) {
+            for (i = 0; i < n; ++i) { double t = QR(i, k); QR(i, k) = QR(i, big); QR(i, big) = t; }
+            { double t = nrm_upd[k]; nrm_upd[k] = nrm_upd[big]; nrm_upd[big] = t; }
+            { double t = nrm_dir[k]; nrm_dir[k] = nrm_dir[big]; nrm_dir[big] = t; }
+        }
+        /* makeHouseholderInPlace on rows k..n-1 of column k, Householder.h:65-94 */
+        tail_sq = (n - k == 1) ? 0.0 : eigen_squared_norm(&QR(k + 1, k), n - k - 1);
+        c0 = QR(k, k);
+        if (tail_sq <= DBL_MIN) {
+            tau = 0;
+            beta = c0;
+            for (i = k + 1; i < n; ++i) QR(i, k) = 0.0;
+        } else {
+            beta = sqrt(c0 * c0 + tail_sq);
+            if (c0 >= 0) beta = -beta;
+            for (i = k + 1; i < n; ++i) QR(i, k) = QR(i, k) / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        hco[k] = tau;
+        QR(k, k) = beta;                                             /* :541 */
+        if (fabs(beta) > maxpivot) maxpivot = fabs(beta);            /* :544 */
+
+        /* applyHouseholderOnTheLeft to rows k.., cols k+1.., Householder.h:113-131 */
+        if (n - k - 1 > 0) {
+            if (n - k == 1) {
+                /* unreachable for square input (no columns remain), kept for shape */
+            } else if (tau != 0) {
+                for (j = k + 1; j < n; ++j) {
+                    double t = 0.0;
+                    for (i = k + 1; i < n; ++i) t += QR(i, k) * QR(i, j);
+                    t += QR(k, j);
+                    tmp[j] = t;
+                }
+                for (j = k + 1; j < n; ++j) QR(k, j) -= tau * tmp[j];
+                for (j = k + 1; j < n; ++j)
+                    for (i = k + 1; i < n; ++i) QR(i, j) -= tau * QR(i, k) * tmp[j];
+            }
+        }
+        /* norm downdate, :551-571 */
+        for (j = k + 1; j < n; ++j) {
+            if (nrm_upd[j] != 0) {
+                double temp = fabs(QR(k, j)) / nrm_upd[j], temp2;
+                temp = (1.0 + temp) * (1.0 - temp);
+                temp = temp < 0 ? 0 : temp;
+                temp2 = temp * ((nrm_upd[j] / nrm_dir[j]) * (nrm_upd[j] / nrm_dir[j]));
+                if (temp2 <= downdate_thr) {
+                    nrm_dir[j] = (n - k - 1 > 0) ? vec_norm(&QR(k + 1, j), n - k - 1) : 0.0;
+                    nrm_upd[j] = nrm_dir[j];
+                } else {
+                    nrm_upd[j] *= sqrt(temp);
+                }
+            }
+        }
+    }
+    for (k = 0; k < n; ++k) perm[k] = k;                             /* :574-576 */
+    for (k = 0; k < n; ++k) { int t = perm[k]; perm[k] = perm[transp[k]]; perm[transp[k]] = t; }
+
+    /* _solve_impl, :585-611 */
+    if (nonzero_pivots == 0) {
+        for (i = 0; i < n; ++i) x[i] = 0.0;
+        return 0;
+    }
+    for (i = 0; i < n; ++i) c[i] = b[i];
+    for (k = 0; k < nonzero_pivots; ++k) {        /* Q^T c = H_{nz-1} ... H_0 c */
+        if (n - k == 1) {
+            c[k] *= 1.0 - hco[k];
+        } else if (hco[k] != 0) {
+            double t = 0.0;
+            for (i = k + 1; i < n; ++i) t += QR(i, k) * c[i];
+            t += c[k];
+            c[k] -= hco[k] * t;
+            for (i = k + 1; i < n; ++i) c[i] -= hco[k] * QR(i, k) * t;
+        }
+    }
+    for (i = nonzero_pivots - 1; i >= 0; --i) {   /* upper-triangular back substitution */
+        c[i] = c[i] / QR(i, i);
+        for (j = 0; j < i; ++j) c[j] -= c[i] * QR(j, i);
+    }
+    for (i = 0; i < nonzero_pivots; ++i) x[perm[i]] = c[i];
+    for (i = nonzero_pivots; i < n; ++i) x[perm[i]] = 0.0;
+#undef QR
+    return nonzero_pivots;
+}
+
+/* ------------------------------------------------------------------ */
+/* moveInteriorPoint, onedpath_ip.cpp:810-953 (F4: onedpath2_ip.cpp:698-841). */
+void orc_step_ex(int variant, double *var, double *d, orc_step_info *info, orc_qr_solver solver)
+{
+    const int m = orc_num_constraints(variant);
+    const int c = NV + m;
+    double mat[MAXN * MAXN], r[MAXN], neg_r[MAXN], trial[ORC3_M];
+    double perturbation, s, r0;
+    int i, nz, feas_h = 0, res_h = 0;
+
+    orc_kkt(variant, var, mat, r, &perturbation);
+    for (i = 0; i < c; ++i) neg_r[i] = -r[i];
+    nz = solver ? solver(c, mat, neg_r, d, 0)                        /* :886-887 */
+                : orc_colpiv_qr_solve(c, mat, neg_r, d);
+
+    s = 1.0;                                                         /* :903-915 */
+    for (i = 0; i < m; ++i) {
+        const double dLm = d[NV + i];
+        if (dLm < 0.0) {
+            const double lmOld = var[NV + i];
+            const double q = -lmOld / dLm;
+            if (q < s) s = q;              /* std::min(s, q) */
+        }
+    }
+    s *= 0.99;
+
+    for (i = 0; i < 100; ++i) {                                      /* :919-928 */
+        trajectory_step(variant, var, d, s, trial);
+        if (orc_constraints_satisfied(variant, trial)) break;
+        s *= 0.5;
+        ++feas_h;
+    }
+
+    r0 = orc_residual_norm(variant, var, perturbation);              /* :932 */
+    for (i = 0; i < 100; ++i) {                                      /* :934-945 */
+        double rn;
+        trajectory_step(variant, var, d, s, trial);
+        rn = orc_residual_norm(variant, trial, perturbation);
+        if (rn <= r0 * (1.0 - 0.01 * s)) break;
+        s *= 0.5;
+        ++res_h;
+    }
+
+    for (i = 0; i < c; ++i) {                                        /* :949-952 */
+        const double di = d[i] * s;
+        var[i] += di;
+    }
+    if (info) {
+        info->feas_halvings = feas_h;
+        info->resid_halvings = res_h;
+        info->nonzero_pivots = nz;
+        info->step_scale = s;
+        info->perturbation = perturbation;
+    }
+}
+
+void orc_step_dir(int variant, double *var, double *d, orc_step_info *info)
+{
+    orc_step_ex(variant, var, d, info, NULL);
+}
+
+void orc_step(int variant, double *var, orc_step_info *info)
+{
+    double d[MAXN];
+    orc_step_ex(variant, var, d, info, NULL);
+}
+
+/* moveTowardFeasibility, onedpath_ip.cpp:648-721 (F4: onedpath2_ip.cpp:536-609):
+ * dX = -G^T (G G^T)^-1 e over the violated rows, QR of the small Gram matrix. */
+void orc_move_toward_feasibility(int variant, double *var)
+{
+    const int m = orc_num_constraints(variant);
+    double err[MAXC], grad[MAXC][3];
+    double g[MAXC][3], e[MAXC], a[MAXC * MAXC], mult[MAXC], dX[3] = {0, 0, 0};
+    int idx[MAXC], n = 0, i, j, k;
+    for (i = 0; i < m; ++i) orc_constraint(variant, i, var, &err[i], grad[i]);
+    for (i = 0; i < m; ++i) if (err[i] > 0) idx[n++] = i;
+    if (n > 0) {
+        for (j = 0; j < n; ++j) {
+            e[j] = err[idx[j]];
+            for (k = 0; k < NV; ++k) g[j][k] = grad[idx[j]][k];
+        }
+        for (i = 0; i < n; ++i)
+            for (j = 0; j < n; ++j) {
+                double acc = 0.0;
+                for (k = 0; k < NV; ++k) acc += g[i][k] * g[j][k];
+                a[(size_t)j * n + i] = acc;
+            }
+        orc_colpiv_qr_solve(n, a, e, mult);
+        for (k = 0; k < NV; ++k) {
+            double acc = 0.0;
+            for (j = 0; j < n; ++j) acc += g[j][k] * -mult[j];
+            dX[k] = acc;
+        }
+    }
+    for (i = 0; i < NV; ++i) var[i] += dX[i];
+}
+
+/* ------------------------------------------------------------------ */
+/* initDefault, onedpath_ip.cpp:201-228 / onedpath2_ip.cpp:164-193 */
+void orc_init_default(int variant, double *var)
+{
+    orc_init_feasible(variant, 0.0, 200.0, 400.0, var);
+    var[ORC3_DUR0] = 3.5;
+    var[ORC3_DUR1] = 3.5;
+}
+
+/* initStuck, onedpath_ip.cpp:177-199 */
+void orc_init_stuck_f3(double *var)
+{
+    var[ORC3_POS0] = 0;    var[ORC3_VEL0] = 0;
+    var[ORC3_POS1] = 350;  var[ORC3_VEL1] = -9.66825;
+    var[ORC3_POS2] = 400;  var[ORC3_VEL2] = 0;
+    var[ORC3_DUR0] = 4.78149;
+    var[ORC3_DUR1] = 4.38968;
+    var[ORC3_LAM0 + 0] = 5.45948e-07;
+    var[ORC3_LAM0 + 1] = 0.00310769;
+    var[ORC3_LAM0 + 2] = 3.49109e-08;
+    var[ORC3_LAM0 + 3] = 0.00281523;
+    var[ORC3_LAM0 + 4] = 8.39344e-07;
+    var[ORC3_LAM0 + 5] = 1.76937e-06;
+    var[ORC3_LAM0 + 6] = 0.0187559;
+    var[ORC3_LAM0 + 7] = 8.42414e-07;
+}
+
+/* Feasible-start rule (build-defined; the reference only has initDefault):
+ * vel1 = 0, t_i = (3.5/sqrt(12)) * sqrt(6 |dX_i| / L), multipliers 1, vel0 = vel2 = 0. */
+void orc_init_feasible(int variant, double pos0, double pos1, double pos2, double *var)
+{
+    const int m = orc_num_constraints(variant);
+    const int base = NV + m;
+    int i;
+    var[ORC3_VEL1] = 0;
+    var[ORC3_DUR0] = (3.5 / sqrt(12.0)) * sqrt(6.0 * fabs(pos1 - pos0) / ACCEL_LIMIT);
+    var[ORC3_DUR1] = (3.5 / sqrt(12.0)) * sqrt(6.0 * fabs(pos2 - pos1) / ACCEL_LIMIT);
+    for (i = 0; i < m; ++i) var[ORC3_LAM0 + i] = 1.0;
+    var[base + 0] = pos0;
+    var[base + 1] = 0;
+    var[base + 2] = pos1;
+    var[base + 3] = pos2;
+    var[base + 4] = 0;
+}
+
+int orc_solve_gated(int variant, double *var, double gap_tol, int max_iter)
+{
+    int it;
+    for (it = 0; it < max_iter; ++it) {
+        if (orc_gap(variant, var) < gap_tol) break;
+        orc_step(variant, var, NULL);
+    }
+    return it;
+}
+
+/* ------------------------------------------------------------------ */
+int orc_hw_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}
+
+static int pick_threads(int threads)
+{
+    const int hw = orc_hw_threads();
+    if (threads <= 0 || threads > hw) return hw;
+    return threads;
+}
+
+void orc_batch_init_feasible(int variant, size_t n, const double *pos0, const double *pos1,
+                             const double *pos2, double *aos)
+{
+    const size_t M = (size_t)orc_state_len(variant);
+    size_t i;
+    for (i = 0; i < n; ++i) orc_init_feasible(variant, pos0[i], pos1[i], pos2[i], aos + i * M);
+}
+
+void orc_batch_steps(int variant, size_t n, double *aos, int k, int threads)
+{
+    const size_t M = (size_t)orc_state_len(variant);
+    const int nt = pick_threads(threads);
+    long long i;
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (i = 0; i < (long long)n; ++i) {
+        int s;
+        for (s = 0; s < k; ++s) orc_step(variant, aos + (size_t)i * M, NULL);
+    }
+}
+
+int64_t orc_batch_solve_gated(int variant, size_t n, double *aos, double gap_tol, int max_iter,
+                              int32_t *iters, int threads)
+{
+    const size_t M = (size_t)orc_state_len(variant);
+    const int nt = pick_threads(threads);
+    int64_t total = 0;
+    long long i;
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static) reduction(+ : total)
+    for (i = 0; i < (long long)n; ++i) {
+        const int it = orc_solve_gated(variant, aos + (size_t)i * M, gap_tol, max_iter);
+        if (iters) iters[i] = it;
+        total += it;
+    }
+    return total;
+}
+
+/* ------------------------------------------------------------------ */
+/* drawSegment sample positions (onedpath_ip.cpp:1065-1088) and plotAcceleration's four
+ * end accelerations (1024-1027).  Note the float literals 3.0f / 2.0f promote exactly. */
+static void sample_segment(double x0, double v0, double x1, double v1, double h, double *out)
+{
+    const double acc0 = (x1 - x0) * (6.0 / sqr(h)) - (v0 * 4.0 + v1 * 2.0) / h;
+    const double jrk0 = (v1 - v0) * (2.0 / sqr(h)) - acc0 * (2.0 / h);
+    int j;
+    out[0] = x0;
+    for (j = 1; j < 32; ++j) {
+        const double t = h * (double)j / 32.0;
+        out[j] = x0 + (v0 + (acc0 + jrk0 * (t / 3.0)) * (t / 2.0)) * t;
+    }
+    out[32] = x1;
+}
+
+void orc_sample_trajectory(int variant, const double *var, double *out_pos, double *out_acc)
+{
+    const seg_consts k = get_consts(variant, var);
+    const double v1 = var[ORC3_VEL1], t0 = var[ORC3_DUR0], t1 = var[ORC3_DUR1];
+    sample_segment(k.pos0, k.vel0, k.pos1, v1, t0, out_pos);
+    sample_segment(k.pos1, v1, k.pos2, k.vel2, t1, out_pos + 33);
+    out_acc[0] = ((k.pos1 - k.pos0) * 6.0 / t0 + k.vel0 * -4.0 + v1 * -2.0) / t0;
+    out_acc[1] = ((k.pos1 - k.pos0) * -6.0 / t0 + k.vel0 * 2.0 + v1 * 4.0) / t0;
+    out_acc[2] = ((k.pos2 - k.pos1) * 6.0 / t1 + v1 * -4.0 + k.vel2 * -2.0) / t1;
+    out_acc[3] = ((k.pos2 - k.pos1) * -6.0 / t1 + v1 * 2.0 + k.vel2 * 4.0) / t1;
+}
+
+/* ------------------------------------------------------------------ */
+/* SplitMix64 counter generator: draw j of problem i is mix(seed + 3 i + j + 1). */
+static uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static double u01(uint64_t seed, uint64_t ctr)
+{
+    return (double)(splitmix64(seed + ctr) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+void orc_gen_problems(uint64_t seed, size_t first, size_t n, int dist,
+                      double *pos0, double *pos1, double *pos2)
+{
+    size_t i;
+    for (i = 0; i < n; ++i) {
+        const uint64_t base = 3ULL * (uint64_t)(first + i);
+        const double u1 = u01(seed, base + 1), u2 = u01(seed, base + 2), u3 = u01(seed, base + 3);
+        if (dist == 0) {            /* monotone (primary) */
+            pos0[i] = 1000.0 * u1;
+            pos1[i] = pos0[i] + 10.0 + 500.0 * u2;
+            pos2[i] = pos1[i] + 10.0 + 500.0 * u3;
+        } else if (dist == 1) {     /* reference-like */
+            pos0[i] = 0.0;
+            pos1[i] = 20.0 + 360.0 * u1;
+            pos2[i] = 400.0;
+        } else {                    /* non-monotone stress */
+            pos0[i] = -500.0 + 1000.0 * u1;
+            pos1[i] = -500.0 + 1000.0 * u2;
+            pos2[i] = -500.0 + 1000.0 * u3;
+        }
+    }
+}
