@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- Newton steps/s of the batched interior-point hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): per GPU a
+batch of 1,048,576 F3 problems (monotone synthetic positions, seed 12345, feasible-start rule
+of SURVEY.md 8d), fp64, each solved until its surrogate duality gap drops below 1e-8 (cap 200
+steps).  One bench "step" = one pass of the hot path over one such batch: the fused gated
+kernel solves every problem of the batch from its start state.  K + W batches are laid out in
+HBM beforehand (positions -> start states, on the device) so that every timed pass streams a
+state it has not touched before, from HBM rather than from the 256 MiB Infinity Cache, and the
+timed region contains nothing but the hot path plus the single final reduction / all-reduce.
+
+N > 1: one process per GPU, rank r owns the contiguous shard r of the N x 1,048,576 problems
+(weak scaling); no step exchanges anything; the only collective is the final 32-byte summary
+all-reduce over RCCL.
+
+Printed by rank 0: ONE JSON line (contract in the task statement), with `roofline` for the
+dominant kernel (k_newton<double,3,gated>), `cpu_baseline` (oracle port, N = 1 only) and two
+labelled extras: `per_step_launch` (the same step as one launch per Newton step, which is the
+HBM-streaming form: 216 B really cross HBM per step) and `fixed50` (configs[1]).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PER_GPU = 1 << 20
+SEED = 12345
+GAP_TOL = 1e-8
+MAX_ITER = 200
+B_ALG_F3 = 216.0          # bytes per problem per Newton step: read 16, write 11 doubles
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(sample_n):
+    """The oracle (C restatement of the reference's CPU step, own 11x11 QR) on the host cores.
+    Reported baseline only -- never the thing measured above."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_api import Oracle
+    from rocket_path_amd import problems
+    orc = Oracle()
+    threads = orc.hw_threads()
+    p0, p1, p2 = problems.generate(SEED, 0, sample_n, problems.DIST_MONOTONE)
+    aos = orc.batch_init_feasible(3, p0, p1, p2)
+    t0 = time.perf_counter()
+    _, total = orc.batch_solve_gated(3, aos, GAP_TOL, MAX_ITER, threads=threads)
+    dt = time.perf_counter() - t0
+    # single-core rate on a smaller slice, for the per-core figure
+    n1 = max(1, sample_n // 32)
+    aos1 = orc.batch_init_feasible(3, p0[:n1], p1[:n1], p2[:n1])
+    t0 = time.perf_counter()
+    _, total1 = orc.batch_solve_gated(3, aos1, GAP_TOL, MAX_ITER, threads=1)
+    dt1 = time.perf_counter() - t0
+    return {"value": total / dt, "unit": "Newton steps/s", "cores": threads, "kind": "port",
+            "sample": "first %d problems of the same batch, same gate, %d steps in %.2f s on %d threads" % (sample_n, total, dt, threads),
+            "single_core_value": total1 / dt1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--problems-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import rocket_path_amd as rp
+    from rocket_path_amd import problems, sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available() or rp.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback to time)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n_total = args.problems_per_gpu * world
+    first, count = problems.shard_range(n_total, rank, world)
+    K, W = args.steps, args.warmup
+
+    # ---- inputs resident in HBM before anything is timed ----
+    p0, p1, p2 = problems.generate(SEED, first, count, problems.DIST_MONOTONE)
+    d_pos = torch.from_numpy(np.stack([p0, p1, p2])).to(torch.device("cuda", local_rank))
+    lead = rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank)
+    stream = lead.stream()
+    batches = [lead] + [rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) for _ in range(K + W - 1)]
+    ptrs = [d_pos[j].data_ptr() for j in range(3)]
+    for b in batches:
+        b.set_problems_device(*ptrs)
+    lead.sync()
+    summary = torch.zeros(4, dtype=torch.float64, device=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup: W untimed passes ----
+    for b in batches[:W]:
+        b.solve(GAP_TOL, MAX_ITER, 0)
+    if world > 1:
+        sharding.allreduce_summary(summary.clone())     # RCCL communicator setup outside the timed region
+    barrier()
+
+    # ---- timed: exactly K passes, then the final summary reduction (+ all-reduce) ----
+    t0 = time.perf_counter()
+    lead.event_record(0)
+    for b in batches[W:]:
+        b.solve(GAP_TOL, MAX_ITER, 0)
+    lead.event_record(1)
+    batches[-1].reduce_device(summary.data_ptr())
+    lead.sync()
+    sharding.allreduce_summary(summary)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = lead.event_elapsed_ms(0, 1) / max(K, 1)
+    steps_local = sum(b.reduce()["total_steps"] for b in batches[W:])
+    conv_local = sum(b.reduce()["n_converged"] for b in batches[W:])
+    t = torch.tensor([elapsed, steps_local, conv_local], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    if world > 1:
+        tm = t[:1].clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ts = t[1:].clone()
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        elapsed, steps_all, conv_all = float(tm[0]), float(ts[0]), float(ts[1])
+    else:
+        steps_all, conv_all = steps_local, conv_local
+    g = sharding.summary_dict(summary)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    steps_per_launch = steps_local / max(K, 1)
+    achieved = B_ALG_F3 * steps_per_launch / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_newton_f3_f64_gated", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "interior-point Newton steps/sec (whole node)",
+        "value": steps_all / elapsed,
+        "unit": "Newton steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / max(K, 1) * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[2] (C3): %d F3 onedpath_ip problems per GPU, convergence-gated "
+                        "(surrogate gap < 1e-8 checked before every step, cap 200), fp64, monotone seeded positions, "
+                        "feasible-start rule; one fused launch per batch" % args.problems_per_gpu,
+            "problems_per_gpu": args.problems_per_gpu,
+            "problems_total": n_total,
+            "newton_steps_per_pass_per_gpu": steps_per_launch,
+            "mean_steps_per_problem": steps_per_launch / count,
+            "converged_fraction": conv_all / (n_total * max(K, 1)),
+            "final_summary": g,
+            "sharding": "contiguous shards, no data-path collective; one 32-byte RCCL all-reduce at the end" if world > 1
+                        else "single GPU",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_newton<double, F3, gated> (fused: state stays in VGPRs between steps)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": B_ALG_F3 * steps_per_launch,
+            "avg_launch_ms": kernel_ms,
+            "note": "algorithmic bytes = 216 B x Newton steps executed in the launch (SURVEY.md 8d); the fused launch "
+                    "moves each state across HBM once per solve, so measured traffic is ~1/15 of this and the kernel "
+                    "is fp64-ALU bound; see per_step_launch for the form in which 216 B/step really cross HBM",
+        },
+    }
+
+    if not args.no_extras:
+        # (a) one launch per Newton step on never-touched batches: the HBM-streaming form of the same step
+        spare = batches[W:]
+        for b in spare:
+            b.set_problems_device(*ptrs)
+        lead.sync()
+        torch.cuda.synchronize()
+        lead.event_record(2)
+        for b in spare:
+            b.step(1)
+        lead.event_record(3)
+        lead.sync()
+        ms1 = lead.event_elapsed_ms(2, 3) / len(spare)
+        gbs = B_ALG_F3 * count / (ms1 * 1e-3) / 1e9
+        line["per_step_launch"] = {"kernel": "k_newton<double, F3, ungated>, k = 1", "avg_launch_ms": ms1,
+                                   "newton_steps_per_s": count / (ms1 * 1e-3), "achieved_GBps": gbs,
+                                   "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "launches": len(spare)}
+        # (b) configs[1]: 65,536 problems, exactly 50 steps each, one fused launch
+        n2 = 65536
+        with rp.Batch(n2, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) as c2:
+            ms = []
+            for _ in range(4):
+                c2.set_problems_device(*ptrs)
+                c2.sync()
+                c2.event_record(4)
+                c2.step(50)
+                c2.event_record(5)
+                c2.sync()
+                ms.append(c2.event_elapsed_ms(4, 5))
+        line["fixed50"] = {"workload": "BASELINE configs[1] (C2): 65,536 problems x exactly 50 steps, one fused launch",
+                           "ms": min(ms[1:]), "newton_steps_per_s": n2 * 50 / (min(ms[1:]) * 1e-3)}
+
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(min(count, 1 << 19))
+    else:
+        line["cpu_baseline"] = None
+
+    print(json.dumps(line))
+    sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+/*
+ * rp_batch.h -- C ABI of the MI355X-native batched interior-point path.
+ *
+ * This is the one boundary between host code (the C++ `Problem` plug-in that drops into
+ * rocket_path.cpp, or the Python mirror used by tests/bench) and the HIP kernels.  Plain
+ * pointers and sizes only; no C++ or torch types cross it.  The library never throws:
+ * every entry point returns an rp_status, and rp_last_error() has the text.
+ *
+ * A batch is N independent problems of one variant:
+ *   RP_VARIANT_F3  two-segment cubic, 3 variables + 8 multipliers, c_i = -/+a - L
+ *                  (replaces the file-static `Trajectory g_trajectory`, onedpath_ip.cpp:47-52)
+ *   RP_VARIANT_F4  same spline, 4 multipliers, c_i = (a^2 - L^2)/2
+ *                  (replaces `Trajectory2 g_trajectory`, onedpath2_ip.cpp:50-55)
+ * Host-visible state is the reference's own array-of-structs layout, `double var[16]`
+ * (enum V, onedpath_ip.cpp:15-43) or `double var[12]` (enum V2, onedpath2_ip.cpp:15-39)
+ * per problem; on the device it is structure-of-arrays in the batch's compute type.
+ *
+ * Threading: a handle is not thread-safe (the reference is single-threaded: one GLUT
+ * thread calls Problem::onKey).  Different handles may be used from different threads.
+ * Calls that enqueue work are asynchronous on the batch's stream unless the doc says
+ * "synchronous"; rp_batch_sync() waits.
+ */
+#ifndef RP_BATCH_H
+#define RP_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define RP_API __attribute__((visibility("default")))
+#else
+#define RP_API
+#endif
+
+typedef struct rp_batch rp_batch; /* opaque, owned by the caller between create and destroy */
+
+typedef enum {
+    RP_OK = 0,
+    RP_ERR_INVALID = 1,     /* bad argument (null handle, unknown variant/dtype, n == 0, ...) */
+    RP_ERR_DEVICE = 2,      /* a HIP call failed; rp_last_error() has hipGetErrorString */
+    RP_ERR_NOMEM = 3,       /* host or device allocation failed */
+    RP_ERR_UNSUPPORTED = 4, /* valid request this build does not implement */
+    RP_ERR_NO_DEVICE = 5    /* no HIP device visible: the product path has no CPU fallback */
+} rp_status;
+
+#define RP_VARIANT_F3 3
+#define RP_VARIANT_F4 4
+#define RP_DTYPE_F64 0
+#define RP_DTYPE_F32 1
+
+/* Per-problem status bits (new; the reference has no error reporting). */
+#define RP_ST_CONVERGED 1u  /* gap < tol seen at a gate check */
+#define RP_ST_MAXITER 2u    /* step cap reached before the gate */
+#define RP_ST_NONFINITE 4u  /* a variable became NaN/inf */
+#define RP_ST_INFEASIBLE 8u /* some c_i > 0 at the last gate check (constraintsSatisfied false) */
+
+/* Solver constants, defaults = the reference's compile-time values. */
+typedef struct {
+    double accel_limit;       /* 100.0   onedpath_ip.cpp:54 */
+    double mu_divisor;        /* 10.0    perturbation = gap / (m * 10), onedpath_ip.cpp:812 */
+    double boundary_fraction; /* 0.99    onedpath_ip.cpp:915 */
+    double backtrack;         /* 0.5     onedpath_ip.cpp:927, 944 */
+    double armijo;            /* 0.01    onedpath_ip.cpp:941 */
+    int32_t max_backtracks;   /* 100     onedpath_ip.cpp:919, 934 */
+    int32_t reserved;
+} rp_params;
+
+/* Batch-wide reduction, the payload of the one cross-GPU collective (max / max / sum / sum). */
+typedef struct {
+    double max_residual_sq; /* max_i ||r_i||^2 with r as residual(), onedpath_ip.cpp:753-792, p = gap_i/(10 m) */
+    double max_gap;         /* max_i surrogateDualityGap, onedpath_ip.cpp:794-808 */
+    double n_converged;     /* problems with RP_ST_CONVERGED (double so one dtype all-reduces) */
+    double total_steps;     /* Newton steps executed since the last init/set_state */
+} rp_reduction;
+
+/* ---- library ---- */
+RP_API const char *rp_version(void);
+RP_API const char *rp_last_error(void); /* thread-local text of the last failure */
+RP_API const char *rp_status_string(int status);
+RP_API int rp_device_count(int *count);
+RP_API void rp_params_default(rp_params *p);
+
+/* ---- lifetime ---- */
+/* `stream` is a hipStream_t the caller owns (e.g. torch's current stream) or NULL for a
+ * stream the batch creates.  `device` is the HIP device ordinal. */
+RP_API int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device, void *stream);
+RP_API int rp_batch_destroy(rp_batch *b);
+RP_API int rp_batch_set_params(rp_batch *b, const rp_params *p);
+RP_API int rp_batch_get_params(const rp_batch *b, rp_params *p);
+RP_API int rp_batch_size(const rp_batch *b, size_t *n);
+RP_API int rp_batch_info(const rp_batch *b, int *variant, int *dtype, int *device);
+
+/* ---- init: Problem::init() / onKey('i') / onKey('j') for every problem of the batch ---- */
+RP_API int rp_batch_init_default(rp_batch *b); /* initDefault, onedpath_ip.cpp:201-228 / onedpath2_ip.cpp:164-193 */
+RP_API int rp_batch_init_stuck(rp_batch *b);   /* initStuck, onedpath_ip.cpp:177-199 (F3 only) */
+/* Per-problem positions (host arrays of n doubles), then the feasible start rule of
+ * SURVEY.md 8d on the device: vel = 0, t_i = (3.5/sqrt 12) sqrt(6 |dX_i| / L), multipliers 1. */
+RP_API int rp_batch_set_problems(rp_batch *b, const double *pos0, const double *pos1, const double *pos2);
+/* Same with device-resident inputs (no PCIe in the path). */
+RP_API int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double *d_pos1, const double *d_pos2);
+/* Whole state in the reference's AoS layout, n * 16 (F3) or n * 12 (F4) doubles.  Synchronous. */
+RP_API int rp_batch_set_state(rp_batch *b, const double *aos);
+RP_API int rp_batch_get_state(rp_batch *b, double *aos);
+/* Special-key nudges (onSpecialKey, onedpath_ip.cpp:280-324): var[index] += delta for all problems. */
+RP_API int rp_batch_nudge(rp_batch *b, int var_index, double delta);
+
+/* ---- the hot path ---- */
+/* k times onKey('n') = moveInteriorPoint (onedpath_ip.cpp:810-953 / onedpath2_ip.cpp:698-841)
+ * on every problem, ungated, fused into one launch (state stays in registers between steps). */
+RP_API int rp_batch_step(rp_batch *b, int k);
+/* Gated solve, the convention of SURVEY.md appendix A.5 per problem:
+ *     for (it = 0; it < max_iter; ++it) { if (gap < gap_tol) break; step; }
+ * steps_per_launch <= 0: one fused launch (each lane loops until its own gate);
+ * steps_per_launch = s > 0: launches of s steps until every problem is done (host polls a
+ * device counter after each launch; synchronous).  Iteration counts accumulate across calls
+ * until the next init/set_state. */
+RP_API int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_launch);
+/* The Space key, moveTowardFeasibility (onedpath_ip.cpp:648-721), on every problem. */
+RP_API int rp_batch_move_toward_feasibility(rp_batch *b);
+
+/* ---- results ---- */
+RP_API int rp_batch_get_iters(rp_batch *b, int32_t *iters, uint32_t *status); /* either may be NULL; synchronous */
+RP_API int rp_batch_reduce(rp_batch *b, rp_reduction *out);                   /* synchronous */
+/* Writes the 4 doubles of rp_reduction to device memory the caller owns, asynchronously on
+ * the batch stream: the buffer a multi-GPU caller hands to its RCCL all-reduce. */
+RP_API int rp_batch_reduce_device(rp_batch *b, double *d_out4);
+/* Plot data (plotTrajectory/plotAcceleration, onedpath_ip.cpp:1015-1088): per problem 66
+ * positions (33 per segment) and 4 end accelerations, host arrays, synchronous. */
+RP_API int rp_batch_sample(rp_batch *b, double *pos66, double *acc4);
+
+/* ---- stream / timing plumbing ---- */
+RP_API int rp_batch_sync(rp_batch *b);
+RP_API int rp_batch_stream(rp_batch *b, void **stream);
+/* HIP events on the batch's own stream: record slot 0..7, elapsed between two recorded slots. */
+RP_API int rp_batch_event_record(rp_batch *b, int slot);
+RP_API int rp_batch_event_elapsed_ms(rp_batch *b, int slot_start, int slot_stop, float *ms);
+/* Device pointer of one SoA field (0..15 / 0..11) for callers that manage their own copies. */
+RP_API int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

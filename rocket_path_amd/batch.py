@@ -1,0 +1,150 @@
+"""Host-side mirror of the batched Problem over the C ABI (include/rp_batch.h).
+
+`Batch` is what the C++ plug-in `BatchedOneDPathIP` (csrc/host/) is to rocket_path.cpp, for
+Python callers (tests, bench): the same entry points with the same meaning,
+    init_default()  = Problem::init() / onKey('i')      (onedpath_ip.cpp:230-233, 259-262)
+    init_stuck()    = onKey('j')                         (onedpath_ip.cpp:264-267)
+    step(k)         = k x onKey('n')                     (onedpath_ip.cpp:269-272)
+    move_toward_feasibility() = onKey(' ')               (onedpath_ip.cpp:254-257)
+    nudge(i, d)     = onSpecialKey                       (onedpath_ip.cpp:280-324)
+and, like the reference, no error returns in the happy path: failures raise RpError.
+State crosses the boundary in the reference's AoS layout (double var[16] / var[12]).
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Batch:
+    def __init__(self, n, variant=capi.VARIANT_F3, dtype=capi.DTYPE_F64, device=0, stream=None):
+        self._lib = capi.load_library()
+        self._h = ctypes.c_void_p()
+        capi.check(self._lib.rp_batch_create(ctypes.byref(self._h), variant, dtype, n, device,
+                                             ctypes.c_void_p(stream) if stream else None))
+        self.n, self.variant, self.dtype, self.device = n, variant, dtype, device
+        self.state_len = 12 if variant == capi.VARIANT_F4 else 16
+        self.num_constraints = 4 if variant == capi.VARIANT_F4 else 8
+
+    # ---- lifetime ----
+    def close(self):
+        if self._h:
+            self._lib.rp_batch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- parameters ----
+    def get_params(self):
+        p = capi.Params()
+        capi.check(self._lib.rp_batch_get_params(self._h, ctypes.byref(p)))
+        return p
+
+    def set_params(self, **kw):
+        p = self.get_params()
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        capi.check(self._lib.rp_batch_set_params(self._h, ctypes.byref(p)))
+
+    # ---- init ----
+    def init_default(self):
+        capi.check(self._lib.rp_batch_init_default(self._h))
+
+    def init_stuck(self):
+        capi.check(self._lib.rp_batch_init_stuck(self._h))
+
+    def set_problems(self, pos0, pos1, pos2):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (pos0, pos1, pos2)]
+        for a in arrs:
+            if a.shape != (self.n,):
+                raise ValueError("position arrays must have shape (%d,)" % self.n)
+        capi.check(self._lib.rp_batch_set_problems(self._h, *[_ptr(a) for a in arrs]))
+
+    def set_problems_device(self, d_pos0, d_pos1, d_pos2):
+        """Device pointers (ints) to n float64 each, e.g. torch tensors' data_ptr()."""
+        capi.check(self._lib.rp_batch_set_problems_device(self._h, *[ctypes.c_void_p(p) for p in (d_pos0, d_pos1, d_pos2)]))
+
+    def set_state(self, aos):
+        a = np.ascontiguousarray(aos, dtype=np.float64)
+        if a.shape != (self.n, self.state_len):
+            raise ValueError("state must have shape (%d, %d)" % (self.n, self.state_len))
+        capi.check(self._lib.rp_batch_set_state(self._h, _ptr(a)))
+
+    def get_state(self):
+        a = np.empty((self.n, self.state_len), dtype=np.float64)
+        capi.check(self._lib.rp_batch_get_state(self._h, _ptr(a)))
+        return a
+
+    def nudge(self, var_index, delta):
+        capi.check(self._lib.rp_batch_nudge(self._h, var_index, float(delta)))
+
+    # ---- hot path ----
+    def step(self, k=1):
+        capi.check(self._lib.rp_batch_step(self._h, int(k)))
+
+    def solve(self, gap_tol=1e-8, max_iter=200, steps_per_launch=0):
+        capi.check(self._lib.rp_batch_solve(self._h, float(gap_tol), int(max_iter), int(steps_per_launch)))
+
+    def move_toward_feasibility(self):
+        capi.check(self._lib.rp_batch_move_toward_feasibility(self._h))
+
+    # ---- results ----
+    def get_iters(self):
+        it = np.empty(self.n, dtype=np.int32)
+        st = np.empty(self.n, dtype=np.uint32)
+        capi.check(self._lib.rp_batch_get_iters(self._h, _ptr(it), _ptr(st)))
+        return it, st
+
+    def reduce(self):
+        r = capi.Reduction()
+        capi.check(self._lib.rp_batch_reduce(self._h, ctypes.byref(r)))
+        return {"max_residual_sq": r.max_residual_sq, "max_gap": r.max_gap,
+                "n_converged": r.n_converged, "total_steps": r.total_steps}
+
+    def reduce_device(self, d_out4):
+        capi.check(self._lib.rp_batch_reduce_device(self._h, ctypes.c_void_p(d_out4)))
+
+    def sample(self):
+        pos = np.empty((self.n, 66), dtype=np.float64)
+        acc = np.empty((self.n, 4), dtype=np.float64)
+        capi.check(self._lib.rp_batch_sample(self._h, _ptr(pos), _ptr(acc)))
+        return pos, acc
+
+    # ---- plumbing ----
+    def sync(self):
+        capi.check(self._lib.rp_batch_sync(self._h))
+
+    def stream(self):
+        s = ctypes.c_void_p()
+        capi.check(self._lib.rp_batch_stream(self._h, ctypes.byref(s)))
+        return s.value
+
+    def event_record(self, slot):
+        capi.check(self._lib.rp_batch_event_record(self._h, slot))
+
+    def event_elapsed_ms(self, start, stop):
+        ms = ctypes.c_float()
+        capi.check(self._lib.rp_batch_event_elapsed_ms(self._h, start, stop, ctypes.byref(ms)))
+        return ms.value
+
+    def field_ptr(self, field):
+        p = ctypes.c_void_p()
+        capi.check(self._lib.rp_batch_field_ptr(self._h, field, ctypes.byref(p)))
+        return p.value

@@ -1,0 +1,107 @@
+"""ctypes binding of the C ABI in include/rp_batch.h (lib/librp_batch.so).
+
+This module is the only place Python touches the product library.  It never falls back to
+anything: if the shared object is missing, or no HIP device is visible when a batch is
+created, it raises.  The oracle under oracle/ is never imported from here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librp_batch.so")
+
+RP_OK = 0
+RP_ERR_INVALID, RP_ERR_DEVICE, RP_ERR_NOMEM, RP_ERR_UNSUPPORTED, RP_ERR_NO_DEVICE = 1, 2, 3, 4, 5
+VARIANT_F3, VARIANT_F4 = 3, 4
+DTYPE_F64, DTYPE_F32 = 0, 1
+ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_INFEASIBLE = 1, 2, 4, 8
+
+
+class RpError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("rp_batch: status %d (%s)" % (status, text))
+        self.status = status
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("accel_limit", ctypes.c_double), ("mu_divisor", ctypes.c_double),
+                ("boundary_fraction", ctypes.c_double), ("backtrack", ctypes.c_double),
+                ("armijo", ctypes.c_double), ("max_backtracks", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class Reduction(ctypes.Structure):
+    _fields_ = [("max_residual_sq", ctypes.c_double), ("max_gap", ctypes.c_double),
+                ("n_converged", ctypes.c_double), ("total_steps", ctypes.c_double)]
+
+
+_vp = ctypes.c_void_p
+_dp = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); every symbol include/rp_batch.h declares
+SIGNATURES = {
+    "rp_version": (ctypes.c_char_p, []),
+    "rp_last_error": (ctypes.c_char_p, []),
+    "rp_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "rp_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "rp_params_default": (None, [ctypes.POINTER(Params)]),
+    "rp_batch_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, _vp]),
+    "rp_batch_destroy": (ctypes.c_int, [_vp]),
+    "rp_batch_set_params": (ctypes.c_int, [_vp, ctypes.POINTER(Params)]),
+    "rp_batch_get_params": (ctypes.c_int, [_vp, ctypes.POINTER(Params)]),
+    "rp_batch_size": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_size_t)]),
+    "rp_batch_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "rp_batch_init_default": (ctypes.c_int, [_vp]),
+    "rp_batch_init_stuck": (ctypes.c_int, [_vp]),
+    "rp_batch_set_problems": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "rp_batch_set_problems_device": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "rp_batch_set_state": (ctypes.c_int, [_vp, _vp]),
+    "rp_batch_get_state": (ctypes.c_int, [_vp, _vp]),
+    "rp_batch_nudge": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
+    "rp_batch_step": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "rp_batch_solve": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
+    "rp_batch_move_toward_feasibility": (ctypes.c_int, [_vp]),
+    "rp_batch_get_iters": (ctypes.c_int, [_vp, _vp, _vp]),
+    "rp_batch_reduce": (ctypes.c_int, [_vp, ctypes.POINTER(Reduction)]),
+    "rp_batch_reduce_device": (ctypes.c_int, [_vp, _vp]),
+    "rp_batch_sample": (ctypes.c_int, [_vp, _vp, _vp]),
+    "rp_batch_sync": (ctypes.c_int, [_vp]),
+    "rp_batch_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "rp_batch_event_record": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "rp_batch_event_elapsed_ms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
+    "rp_batch_field_ptr": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_vp)]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load librp_batch.so and bind every declared symbol.  Raises if the build is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C rocket_path_amd/csrc`. There is no CPU fallback for this path." % p)
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status):
+    if status != RP_OK:
+        lib = load_library()
+        raise RpError(status, (lib.rp_last_error() or b"").decode() or lib.rp_status_string(status).decode())
+
+
+def device_count():
+    """Number of visible HIP devices (0 when there is none)."""
+    n = ctypes.c_int(0)
+    load_library().rp_device_count(ctypes.byref(n))
+    return n.value

@@ -1,0 +1,54 @@
+// ip_kernels.h -- host-callable launchers of the HIP kernels (internal; the public surface
+// is include/rp_batch.h).  All launchers enqueue on `stream` and return the hipError_t of
+// the launch; none synchronises.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace rp {
+
+// Device-side view of one batch: `fields` SoA arrays of `n` elements, field f at
+// base + f * stride (stride >= n, multiple of 256 elements so every field is 1-2 KiB aligned).
+struct BatchView {
+    void *base;            // double* or float*
+    size_t stride;         // elements between consecutive fields
+    size_t n;              // problems
+    int variant;           // 3 or 4
+    int dtype;             // 0 = f64, 1 = f32
+    int32_t *iters;        // gated Newton steps taken per problem
+    uint32_t *status;      // RP_ST_* bits per problem
+    unsigned long long *counters;   // [0] problems still active after the last gated launch, [1] gated steps executed
+};
+
+struct HostParams {
+    double accel_limit, mu_divisor, boundary_fraction, backtrack, armijo;
+    int max_backtracks;
+};
+
+inline int state_len(int variant) { return variant == 4 ? 12 : 16; }
+inline int num_constraints(int variant) { return variant == 4 ? 4 : 8; }
+
+// k ungated Newton steps per problem, one launch.
+hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStream_t stream);
+// up to k gated steps per problem (k = max_iter gives the fused solve); zeroes counters[0] first.
+hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream);
+// max ||r||^2, max gap, #converged, gated steps (+ host_steps) -> d_out4 (device); d_partials has 4 * 1024 doubles.
+hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_steps, double *d_partials,
+                         double *d_out4, hipStream_t stream);
+
+// state movement / initialisation
+hipError_t launch_aos_to_soa(const BatchView &b, const double *d_aos, hipStream_t stream);
+hipError_t launch_soa_to_aos(const BatchView &b, double *d_aos, hipStream_t stream);
+hipError_t launch_init_feasible(const BatchView &b, const HostParams &hp, const double *d_pos0, const double *d_pos1,
+                                const double *d_pos2, hipStream_t stream);
+hipError_t launch_init_const(const BatchView &b, const double *host_state /* state_len values */, hipStream_t stream);
+hipError_t launch_nudge(const BatchView &b, int field, double delta, hipStream_t stream);
+hipError_t launch_clear_progress(const BatchView &b, hipStream_t stream);
+
+// the rows either side of the hot path
+hipError_t launch_move_toward_feasibility(const BatchView &b, const HostParams &hp, hipStream_t stream);
+hipError_t launch_sample(const BatchView &b, double *d_pos66, double *d_acc4, hipStream_t stream);
+
+}  // namespace rp

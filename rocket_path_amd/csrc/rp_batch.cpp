@@ -1,0 +1,454 @@
+// rp_batch.cpp -- implementation of the C ABI in include/rp_batch.h over the HIP kernels.
+//
+// Owns, per batch: the SoA state in HBM (one allocation, `fields` arrays of `stride`
+// elements), the per-problem progress words, a small scratch for reductions and the
+// AoS staging buffer used by set_state/get_state.  No CPU fallback exists: without a HIP
+// device every entry point that needs one fails with RP_ERR_NO_DEVICE.
+#include "../../include/rp_batch.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ip_kernels.h"
+
+struct rp_batch {
+    rp::BatchView view;
+    rp::HostParams params;
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    double *d_scratch;        // [0..4095] block partials, [4096..4099] reduction result
+    double *d_aos;            // lazily allocated n * state_len doubles
+    double *d_pos;            // lazily allocated 3 * n doubles (set_problems staging)
+    double ungated_steps;     // per-problem count of ungated steps since the last init
+    hipEvent_t events[8];
+    bool event_live[8];
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+#define RP_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? RP_ERR_NOMEM : RP_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define RP_NEED(b)                                                  \
+    do {                                                            \
+        if (!(b)) return fail(RP_ERR_INVALID, "null batch handle"); \
+        RP_HIP(hipSetDevice((b)->device));                          \
+    } while (0)
+
+size_t elem_size(int dtype) { return dtype == RP_DTYPE_F32 ? 4 : 8; }
+
+void default_params(rp::HostParams &hp)
+{
+    hp.accel_limit = 100.0;
+    hp.mu_divisor = 10.0;
+    hp.boundary_fraction = 0.99;
+    hp.backtrack = 0.5;
+    hp.armijo = 0.01;
+    hp.max_backtracks = 100;
+}
+
+int reset_progress(rp_batch *b)
+{
+    b->ungated_steps = 0.0;
+    RP_HIP(rp::launch_clear_progress(b->view, b->stream));
+    return RP_OK;
+}
+
+int need_aos(rp_batch *b)
+{
+    if (!b->d_aos) RP_HIP(hipMalloc((void **)&b->d_aos, b->view.n * rp::state_len(b->view.variant) * sizeof(double)));
+    return RP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rp_version(void) { return "rocket_path_amd 0.1 (gfx950)"; }
+const char *rp_last_error(void) { return g_err; }
+
+const char *rp_status_string(int status)
+{
+    switch (status) {
+    case RP_OK: return "ok";
+    case RP_ERR_INVALID: return "invalid argument";
+    case RP_ERR_DEVICE: return "HIP error";
+    case RP_ERR_NOMEM: return "out of memory";
+    case RP_ERR_UNSUPPORTED: return "unsupported";
+    case RP_ERR_NO_DEVICE: return "no HIP device (this path has no CPU fallback)";
+    default: return "unknown status";
+    }
+}
+
+int rp_device_count(int *count)
+{
+    if (!count) return fail(RP_ERR_INVALID, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return fail(RP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return RP_OK;
+}
+
+void rp_params_default(rp_params *p)
+{
+    if (!p) return;
+    rp::HostParams hp;
+    default_params(hp);
+    p->accel_limit = hp.accel_limit;
+    p->mu_divisor = hp.mu_divisor;
+    p->boundary_fraction = hp.boundary_fraction;
+    p->backtrack = hp.backtrack;
+    p->armijo = hp.armijo;
+    p->max_backtracks = hp.max_backtracks;
+    p->reserved = 0;
+}
+
+int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device, void *stream)
+{
+    if (!out) return fail(RP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (variant != RP_VARIANT_F3 && variant != RP_VARIANT_F4) return fail(RP_ERR_INVALID, "variant %d (want 3 or 4)", variant);
+    if (dtype != RP_DTYPE_F64 && dtype != RP_DTYPE_F32) return fail(RP_ERR_INVALID, "dtype %d (want 0 = f64 or 1 = f32)", dtype);
+    if (n == 0) return fail(RP_ERR_INVALID, "empty batch");
+    int count = 0;
+    int st = rp_device_count(&count);
+    if (st != RP_OK || count == 0) return fail(RP_ERR_NO_DEVICE, "no HIP device visible; the interior-point path runs on the GPU only");
+    if (device < 0 || device >= count) return fail(RP_ERR_INVALID, "device %d out of range (%d visible)", device, count);
+    RP_HIP(hipSetDevice(device));
+
+    rp_batch *b = new (std::nothrow) rp_batch();
+    if (!b) return fail(RP_ERR_NOMEM, "host allocation failed");
+    std::memset(b, 0, sizeof *b);
+    b->device = device;
+    default_params(b->params);
+    b->view.n = n;
+    b->view.variant = variant;
+    b->view.dtype = dtype;
+    b->view.stride = (n + 255) / 256 * 256;
+    const size_t fields = (size_t)rp::state_len(variant);
+
+    hipError_t e = hipSuccess;
+    if (stream) { b->stream = (hipStream_t)stream; b->own_stream = false; }
+    else { e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking); b->own_stream = (e == hipSuccess); }
+    if (e == hipSuccess) e = hipMalloc(&b->view.base, fields * b->view.stride * elem_size(dtype));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->view.iters, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->view.status, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->view.counters, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_scratch, (4096 + 4) * sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(b->view.base, 0, fields * b->view.stride * elem_size(dtype), b->stream);
+    if (e == hipSuccess) e = rp::launch_clear_progress(b->view, b->stream);
+    if (e != hipSuccess) {
+        const int code = fail(e == hipErrorOutOfMemory ? RP_ERR_NOMEM : RP_ERR_DEVICE, "rp_batch_create: %s", hipGetErrorString(e));
+        rp_batch_destroy(b);
+        return code;
+    }
+    *out = b;
+    return RP_OK;
+}
+
+int rp_batch_destroy(rp_batch *b)
+{
+    if (!b) return RP_OK;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (int i = 0; i < 8; ++i) if (b->event_live[i]) (void)hipEventDestroy(b->events[i]);
+    if (b->view.base) (void)hipFree(b->view.base);
+    if (b->view.iters) (void)hipFree(b->view.iters);
+    if (b->view.status) (void)hipFree(b->view.status);
+    if (b->view.counters) (void)hipFree(b->view.counters);
+    if (b->d_scratch) (void)hipFree(b->d_scratch);
+    if (b->d_aos) (void)hipFree(b->d_aos);
+    if (b->d_pos) (void)hipFree(b->d_pos);
+    if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return RP_OK;
+}
+
+int rp_batch_set_params(rp_batch *b, const rp_params *p)
+{
+    if (!b || !p) return fail(RP_ERR_INVALID, "null argument");
+    if (!(p->accel_limit > 0) || !(p->mu_divisor > 0) || !(p->boundary_fraction > 0 && p->boundary_fraction <= 1) ||
+        !(p->backtrack > 0 && p->backtrack < 1) || !(p->armijo >= 0 && p->armijo < 1) || p->max_backtracks < 0)
+        return fail(RP_ERR_INVALID, "parameter out of range");
+    b->params.accel_limit = p->accel_limit;
+    b->params.mu_divisor = p->mu_divisor;
+    b->params.boundary_fraction = p->boundary_fraction;
+    b->params.backtrack = p->backtrack;
+    b->params.armijo = p->armijo;
+    b->params.max_backtracks = p->max_backtracks;
+    return RP_OK;
+}
+
+int rp_batch_get_params(const rp_batch *b, rp_params *p)
+{
+    if (!b || !p) return fail(RP_ERR_INVALID, "null argument");
+    p->accel_limit = b->params.accel_limit;
+    p->mu_divisor = b->params.mu_divisor;
+    p->boundary_fraction = b->params.boundary_fraction;
+    p->backtrack = b->params.backtrack;
+    p->armijo = b->params.armijo;
+    p->max_backtracks = b->params.max_backtracks;
+    p->reserved = 0;
+    return RP_OK;
+}
+
+int rp_batch_size(const rp_batch *b, size_t *n)
+{
+    if (!b || !n) return fail(RP_ERR_INVALID, "null argument");
+    *n = b->view.n;
+    return RP_OK;
+}
+
+int rp_batch_info(const rp_batch *b, int *variant, int *dtype, int *device)
+{
+    if (!b) return fail(RP_ERR_INVALID, "null batch handle");
+    if (variant) *variant = b->view.variant;
+    if (dtype) *dtype = b->view.dtype;
+    if (device) *device = b->device;
+    return RP_OK;
+}
+
+// initDefault: pos (0, 200, 400), zero velocities, durations 3.5, multipliers 1
+// (onedpath_ip.cpp:201-228, onedpath2_ip.cpp:164-193).
+int rp_batch_init_default(rp_batch *b)
+{
+    RP_NEED(b);
+    double s[16];
+    const int m = rp::num_constraints(b->view.variant);
+    s[0] = 0.0; s[1] = 3.5; s[2] = 3.5;
+    for (int i = 0; i < m; ++i) s[3 + i] = 1.0;
+    s[3 + m + 0] = 0.0; s[3 + m + 1] = 0.0; s[3 + m + 2] = 200.0; s[3 + m + 3] = 400.0; s[3 + m + 4] = 0.0;
+    RP_HIP(rp::launch_init_const(b->view, s, b->stream));
+    return reset_progress(b);
+}
+
+// initStuck, onedpath_ip.cpp:177-199.
+int rp_batch_init_stuck(rp_batch *b)
+{
+    RP_NEED(b);
+    if (b->view.variant != RP_VARIANT_F3) return fail(RP_ERR_UNSUPPORTED, "the stuck state exists for F3 only (onedpath_ip.cpp:177-199)");
+    const double s[16] = {-9.66825, 4.78149, 4.38968,
+                          5.45948e-07, 0.00310769, 3.49109e-08, 0.00281523, 8.39344e-07, 1.76937e-06, 0.0187559, 8.42414e-07,
+                          0.0, 0.0, 350.0, 400.0, 0.0};
+    RP_HIP(rp::launch_init_const(b->view, s, b->stream));
+    return reset_progress(b);
+}
+
+int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double *d_pos1, const double *d_pos2)
+{
+    RP_NEED(b);
+    if (!d_pos0 || !d_pos1 || !d_pos2) return fail(RP_ERR_INVALID, "null position array");
+    RP_HIP(rp::launch_init_feasible(b->view, b->params, d_pos0, d_pos1, d_pos2, b->stream));
+    return reset_progress(b);
+}
+
+int rp_batch_set_problems(rp_batch *b, const double *pos0, const double *pos1, const double *pos2)
+{
+    RP_NEED(b);
+    if (!pos0 || !pos1 || !pos2) return fail(RP_ERR_INVALID, "null position array");
+    const size_t n = b->view.n;
+    if (!b->d_pos) RP_HIP(hipMalloc((void **)&b->d_pos, 3 * n * sizeof(double)));
+    RP_HIP(hipMemcpyAsync(b->d_pos, pos0, n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    RP_HIP(hipMemcpyAsync(b->d_pos + n, pos1, n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    RP_HIP(hipMemcpyAsync(b->d_pos + 2 * n, pos2, n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    int st = rp_batch_set_problems_device(b, b->d_pos, b->d_pos + n, b->d_pos + 2 * n);
+    if (st != RP_OK) return st;
+    RP_HIP(hipStreamSynchronize(b->stream));   // the host arrays may be reused on return
+    return RP_OK;
+}
+
+int rp_batch_set_state(rp_batch *b, const double *aos)
+{
+    RP_NEED(b);
+    if (!aos) return fail(RP_ERR_INVALID, "null state array");
+    int st = need_aos(b);
+    if (st != RP_OK) return st;
+    const size_t bytes = b->view.n * rp::state_len(b->view.variant) * sizeof(double);
+    RP_HIP(hipMemcpyAsync(b->d_aos, aos, bytes, hipMemcpyHostToDevice, b->stream));
+    RP_HIP(rp::launch_aos_to_soa(b->view, b->d_aos, b->stream));
+    st = reset_progress(b);
+    if (st != RP_OK) return st;
+    RP_HIP(hipStreamSynchronize(b->stream));
+    return RP_OK;
+}
+
+int rp_batch_get_state(rp_batch *b, double *aos)
+{
+    RP_NEED(b);
+    if (!aos) return fail(RP_ERR_INVALID, "null state array");
+    int st = need_aos(b);
+    if (st != RP_OK) return st;
+    const size_t bytes = b->view.n * rp::state_len(b->view.variant) * sizeof(double);
+    RP_HIP(rp::launch_soa_to_aos(b->view, b->d_aos, b->stream));
+    RP_HIP(hipMemcpyAsync(aos, b->d_aos, bytes, hipMemcpyDeviceToHost, b->stream));
+    RP_HIP(hipStreamSynchronize(b->stream));
+    return RP_OK;
+}
+
+int rp_batch_nudge(rp_batch *b, int var_index, double delta)
+{
+    RP_NEED(b);
+    if (var_index < 0 || var_index >= rp::state_len(b->view.variant)) return fail(RP_ERR_INVALID, "variable index %d out of range", var_index);
+    RP_HIP(rp::launch_nudge(b->view, var_index, delta, b->stream));
+    return RP_OK;
+}
+
+int rp_batch_step(rp_batch *b, int k)
+{
+    RP_NEED(b);
+    if (k < 0) return fail(RP_ERR_INVALID, "negative step count");
+    if (k == 0) return RP_OK;
+    RP_HIP(rp::launch_steps(b->view, b->params, k, b->stream));
+    b->ungated_steps += (double)k;
+    return RP_OK;
+}
+
+int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_launch)
+{
+    RP_NEED(b);
+    if (max_iter < 0) return fail(RP_ERR_INVALID, "negative max_iter");
+    if (!(gap_tol == gap_tol)) return fail(RP_ERR_INVALID, "gap_tol is NaN");
+    if (steps_per_launch <= 0) {
+        RP_HIP(rp::launch_solve(b->view, b->params, max_iter > 0 ? max_iter : 1, gap_tol, max_iter, b->stream));
+        return RP_OK;
+    }
+    // bounded host loop: every launch either finishes a problem or advances it by >= 1 step
+    const int max_launches = max_iter / steps_per_launch + 2;
+    for (int l = 0; l < max_launches; ++l) {
+        unsigned long long open = 0;
+        RP_HIP(rp::launch_solve(b->view, b->params, steps_per_launch, gap_tol, max_iter, b->stream));
+        RP_HIP(hipMemcpyAsync(&open, b->view.counters, sizeof open, hipMemcpyDeviceToHost, b->stream));
+        RP_HIP(hipStreamSynchronize(b->stream));
+        if (open == 0) break;
+    }
+    return RP_OK;
+}
+
+int rp_batch_move_toward_feasibility(rp_batch *b)
+{
+    RP_NEED(b);
+    RP_HIP(rp::launch_move_toward_feasibility(b->view, b->params, b->stream));
+    return RP_OK;
+}
+
+int rp_batch_get_iters(rp_batch *b, int32_t *iters, uint32_t *status)
+{
+    RP_NEED(b);
+    const size_t n = b->view.n;
+    if (iters) RP_HIP(hipMemcpyAsync(iters, b->view.iters, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    if (status) RP_HIP(hipMemcpyAsync(status, b->view.status, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    RP_HIP(hipStreamSynchronize(b->stream));
+    if (iters && b->ungated_steps > 0) {
+        const int32_t add = (int32_t)b->ungated_steps;
+        for (size_t i = 0; i < n; ++i) iters[i] += add;
+    }
+    return RP_OK;
+}
+
+int rp_batch_reduce_device(rp_batch *b, double *d_out4)
+{
+    RP_NEED(b);
+    if (!d_out4) return fail(RP_ERR_INVALID, "null output");
+    RP_HIP(rp::launch_reduce(b->view, b->params, b->ungated_steps * (double)b->view.n, b->d_scratch, d_out4, b->stream));
+    return RP_OK;
+}
+
+int rp_batch_reduce(rp_batch *b, rp_reduction *out)
+{
+    RP_NEED(b);
+    if (!out) return fail(RP_ERR_INVALID, "null output");
+    double h[4];
+    int st = rp_batch_reduce_device(b, b->d_scratch + 4096);
+    if (st != RP_OK) return st;
+    RP_HIP(hipMemcpyAsync(h, b->d_scratch + 4096, sizeof h, hipMemcpyDeviceToHost, b->stream));
+    RP_HIP(hipStreamSynchronize(b->stream));
+    out->max_residual_sq = h[0];
+    out->max_gap = h[1];
+    out->n_converged = h[2];
+    out->total_steps = h[3];
+    return RP_OK;
+}
+
+int rp_batch_sample(rp_batch *b, double *pos66, double *acc4)
+{
+    RP_NEED(b);
+    if (!pos66 || !acc4) return fail(RP_ERR_INVALID, "null output");
+    const size_t n = b->view.n;
+    double *d = nullptr;
+    RP_HIP(hipMalloc((void **)&d, n * 70 * sizeof(double)));
+    hipError_t e = rp::launch_sample(b->view, d, d + n * 66, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pos66, d, n * 66 * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(acc4, d + n * 66, n * 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RP_ERR_DEVICE, "rp_batch_sample: %s", hipGetErrorString(e));
+    return RP_OK;
+}
+
+int rp_batch_sync(rp_batch *b)
+{
+    RP_NEED(b);
+    RP_HIP(hipStreamSynchronize(b->stream));
+    return RP_OK;
+}
+
+int rp_batch_stream(rp_batch *b, void **stream)
+{
+    if (!b || !stream) return fail(RP_ERR_INVALID, "null argument");
+    *stream = (void *)b->stream;
+    return RP_OK;
+}
+
+int rp_batch_event_record(rp_batch *b, int slot)
+{
+    RP_NEED(b);
+    if (slot < 0 || slot >= 8) return fail(RP_ERR_INVALID, "event slot %d out of range", slot);
+    if (!b->event_live[slot]) {
+        RP_HIP(hipEventCreate(&b->events[slot]));
+        b->event_live[slot] = true;
+    }
+    RP_HIP(hipEventRecord(b->events[slot], b->stream));
+    return RP_OK;
+}
+
+int rp_batch_event_elapsed_ms(rp_batch *b, int slot_start, int slot_stop, float *ms)
+{
+    RP_NEED(b);
+    if (!ms || slot_start < 0 || slot_start >= 8 || slot_stop < 0 || slot_stop >= 8 || !b->event_live[slot_start] || !b->event_live[slot_stop])
+        return fail(RP_ERR_INVALID, "events not recorded");
+    RP_HIP(hipEventSynchronize(b->events[slot_stop]));
+    RP_HIP(hipEventElapsedTime(ms, b->events[slot_start], b->events[slot_stop]));
+    return RP_OK;
+}
+
+int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr)
+{
+    if (!b || !d_ptr) return fail(RP_ERR_INVALID, "null argument");
+    if (field < 0 || field >= rp::state_len(b->view.variant)) return fail(RP_ERR_INVALID, "field %d out of range", field);
+    *d_ptr = (char *)b->view.base + (size_t)field * b->view.stride * elem_size(b->view.dtype);
+    return RP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+"""Data-parallel sharding of a batch over the GPUs of a node.
+
+Problems never interact (moveInteriorPoint touches only its own Trajectory,
+onedpath_ip.cpp:810-953), so rank r simply owns the contiguous range shard_range(n, r, W) in
+its own HBM and no step exchanges anything.  The one collective of the path is the final
+summary: max ||r||^2 and max gap (MAX), converged count and Newton steps (SUM) -- 32 bytes,
+all-reduced with RCCL over xGMI (torch.distributed backend "nccl") or gloo on CPU in tests.
+"""
+import torch
+import torch.distributed as dist
+
+from .problems import shard_range  # noqa: F401  (re-exported)
+
+SUMMARY_FIELDS = ("max_residual_sq", "max_gap", "n_converged", "total_steps")
+
+
+def allreduce_summary(local4, group=None):
+    """In-place reduce of the 4-double summary tensor [max_r2, max_gap, n_conv, steps]."""
+    if local4.numel() != 4 or local4.dtype != torch.float64:
+        raise ValueError("summary must be 4 float64 values")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local4[:2], op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(local4[2:], op=dist.ReduceOp.SUM, group=group)
+    return local4
+
+
+def summary_dict(t4):
+    return {k: float(v) for k, v in zip(SUMMARY_FIELDS, t4.tolist())}
+
+
+def batch_summary(batch, device=None, group=None):
+    """Device-side reduction of `batch` into a torch tensor, then the cross-rank all-reduce.
+
+    The kernel writes straight into the tensor RCCL reduces: no host round trip."""
+    dev = device if device is not None else torch.device("cuda", batch.device)
+    out = torch.empty(4, dtype=torch.float64, device=dev)
+    batch.reduce_device(out.data_ptr())
+    batch.sync()          # the batch runs on its own stream; the collective runs on torch's
+    return allreduce_summary(out, group)

@@ -1,0 +1,91 @@
+"""The C-ABI library: it loads without a GPU, exports every symbol include/rp_batch.h
+declares, and refuses to compute (loudly) when no HIP device is present."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import rocket_path_amd as rp
+from rocket_path_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rp_batch.h")).read()
+    return sorted(set(re.findall(r"RP_API\s+[\w\s\*]+?\b(rp_\w+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    names = _declared_symbols()
+    assert len(names) >= 30
+    assert sorted(capi.SIGNATURES) == names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load_library()
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    # nothing else leaks out of the shared object (kernels and helpers are hidden)
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert {e for e in exported if e.startswith("rp_")} == set(_declared_symbols())
+    assert not [e for e in exported if "newton" in e or "oracle" in e or "orc_" in e]
+
+
+def test_version_status_strings_and_defaults():
+    lib = capi.load_library()
+    assert b"gfx950" in lib.rp_version()
+    assert lib.rp_status_string(capi.RP_OK) == b"ok"
+    assert b"no CPU fallback" in lib.rp_status_string(capi.RP_ERR_NO_DEVICE)
+    p = capi.Params()
+    lib.rp_params_default(ctypes.byref(p))
+    # the reference's compile-time constants (onedpath_ip.cpp:54, 812, 915, 927, 941, 919)
+    assert (p.accel_limit, p.mu_divisor, p.boundary_fraction, p.backtrack, p.armijo, p.max_backtracks) == \
+        (100.0, 10.0, 0.99, 0.5, 0.01, 100)
+
+
+def test_invalid_arguments_are_rejected_without_a_device():
+    lib = capi.load_library()
+    h = ctypes.c_void_p()
+    assert lib.rp_batch_create(ctypes.byref(h), 5, 0, 10, 0, None) == capi.RP_ERR_INVALID
+    assert b"variant" in lib.rp_last_error()
+    assert lib.rp_batch_create(ctypes.byref(h), 3, 7, 10, 0, None) == capi.RP_ERR_INVALID
+    assert lib.rp_batch_create(ctypes.byref(h), 3, 0, 0, 0, None) == capi.RP_ERR_INVALID
+    assert lib.rp_batch_create(None, 3, 0, 1, 0, None) == capi.RP_ERR_INVALID
+    assert lib.rp_batch_step(None, 1) == capi.RP_ERR_INVALID
+    assert lib.rp_batch_destroy(None) == capi.RP_OK
+    n = ctypes.c_size_t()
+    assert lib.rp_batch_size(None, ctypes.byref(n)) == capi.RP_ERR_INVALID
+
+
+@pytest.mark.skipif(rp.device_count() > 0, reason="a GPU is present: the no-device path cannot be exercised")
+def test_no_device_means_loud_failure_not_a_cpu_fallback():
+    with pytest.raises(rp.RpError) as e:
+        rp.Batch(16)
+    assert e.value.status == capi.RP_ERR_NO_DEVICE
+    # the product package never imports the oracle
+    import sys
+    assert not [m for m in sys.modules if "oracle" in m and "rocket_path_amd" in m]
+    src = "".join(open(os.path.join(ROOT, "rocket_path_amd", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "rocket_path_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "oracle_api" not in src and "libip_oracle" not in src
+
+
+def test_missing_extension_raises(tmp_path):
+    with pytest.raises(RuntimeError) as e:
+        capi.load_library(str(tmp_path / "nope.so"))
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_headless_shell_without_gpu_fails_cleanly():
+    exe = os.path.join(ROOT, "rocket_path_amd", "lib", "rp_headless")
+    if not os.path.exists(exe):
+        pytest.skip("host layer not built")
+    if rp.device_count() > 0:
+        pytest.skip("GPU present")
+    r = subprocess.run([exe, "--keys", "n s"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr

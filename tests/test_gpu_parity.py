@@ -1,0 +1,341 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Tolerances (BASELINE.json north_star): converged (duration, velocity) within 1e-10 relative,
+identical iteration counts.  "Relative" is scale-aware, |d| <= tol * max(|x|, 1), because
+non-monotone problems converge to vel1 ~ 1e-13 where a plain ratio is meaningless
+(SURVEY.md section 7).  Golden data come from the restatement driven by the reference's own
+Eigen QR (oracle/gen_golden.py); the live oracle uses its own Householder QR.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import rocket_path_amd as rp
+from oracle_api import StepInfo
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-10
+
+
+def serr(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+
+
+@pytest.fixture(scope="module")
+def g3(golden_dir):
+    return np.load(os.path.join(golden_dir, "f3_batch.npz"))
+
+
+@pytest.fixture(scope="module")
+def traj(golden_dir):
+    return np.load(os.path.join(golden_dir, "f3_trajectories.npz"))
+
+
+# ---------------------------------------------------------------- config 1: the single default problem
+def test_config1_default_problem_50_steps(traj):
+    with rp.Batch(1) as b:
+        b.init_default()
+        s0 = b.get_state()[0]
+        assert np.array_equal(s0[:11], traj["default_states"][0]) and np.array_equal(s0[11:], traj["default_const"])
+        for s in range(1, 51):
+            b.step(1)
+            st = b.get_state()[0]
+            assert np.all(np.isfinite(st)), s
+            assert serr(st[:3], traj["default_states"][s, :3]) < TOL, s
+            if s <= 20:   # multipliers too while they are above the noise floor
+                assert serr(st[3:11], traj["default_states"][s, 3:11]) < 1e-9, s
+        assert serr(st[:3], [200.0, 2.0, 2.0]) < 1e-13
+        it, status = b.get_iters()
+        assert it[0] == 50
+
+
+def test_fused_steps_equal_single_steps_bitwise(g3):
+    n = 1024
+    init = g3["init"][:n]
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_state(init)
+        b.set_state(init)
+        a.step(7)
+        for _ in range(7):
+            b.step(1)
+        assert np.array_equal(a.get_state(), b.get_state())
+
+
+# ---------------------------------------------------------------- golden batch, fixed steps (config 2 shape)
+def test_fixed_steps_against_golden(g3):
+    n = len(g3["init"])
+    with rp.Batch(n) as b:
+        b.set_state(g3["init"])
+        assert np.array_equal(b.get_state(), g3["init"])          # AoS -> SoA -> AoS is lossless in f64
+        b.step(1)
+        assert serr(b.get_state()[:, :3], g3["after1"][:, :3]) < TOL
+        b.step(4)
+        assert serr(b.get_state()[:, :3], g3["after5"][:, :3]) < TOL
+        b.step(45)
+        st = b.get_state()
+        assert np.all(np.isfinite(st))
+        assert serr(st[:, :3], g3["after50"][:, :3]) < TOL
+
+
+def test_set_problems_applies_the_feasible_start_rule(g3):
+    pos = g3["pos"]
+    with rp.Batch(len(pos)) as b:
+        b.set_problems(pos[:, 0], pos[:, 1], pos[:, 2])
+        st = b.get_state()
+        assert np.array_equal(st[:, 11:], g3["init"][:, 11:])
+        assert np.array_equal(st[:, [0, 3, 4, 5, 6, 7, 8, 9, 10]], g3["init"][:, [0, 3, 4, 5, 6, 7, 8, 9, 10]])
+        assert serr(st[:, 1:3], g3["init"][:, 1:3]) < 4e-16         # device sqrt/div vs libm: last-bit only
+
+
+# ---------------------------------------------------------------- golden batch, gated (config 3 shape)
+@pytest.mark.parametrize("steps_per_launch", [0, 1, 4])
+def test_gated_solve_against_golden(g3, steps_per_launch):
+    n = len(g3["init"])
+    with rp.Batch(n) as b:
+        b.set_state(g3["init"])
+        b.solve(1e-8, 200, steps_per_launch)
+        b.sync()
+        it, status = b.get_iters()
+        st = b.get_state()
+        assert np.array_equal(it, g3["iters"])                      # identical iteration counts
+        assert serr(st[:, :3], g3["gated"][:, :3]) < TOL
+        assert np.all(status == rp.ST_CONVERGED)
+        r = b.reduce()
+        assert r["n_converged"] == n and r["total_steps"] == float(g3["iters"].sum())
+        assert r["max_gap"] < 1e-8
+
+
+def test_fused_and_per_launch_solves_are_bitwise_identical(g3):
+    n = 2048
+    with rp.Batch(n) as a, rp.Batch(n) as b, rp.Batch(n) as c:
+        for x in (a, b, c):
+            x.set_state(g3["init"][:n])
+        a.solve(1e-8, 200, 0)
+        b.solve(1e-8, 200, 1)
+        c.solve(1e-8, 200, 5)
+        sa, sb, sc = a.get_state(), b.get_state(), c.get_state()
+        assert np.array_equal(sa, sb) and np.array_equal(sa, sc)
+        assert np.array_equal(a.get_iters()[0], b.get_iters()[0]) and np.array_equal(a.get_iters()[0], c.get_iters()[0])
+
+
+def test_solve_is_idempotent_and_respects_max_iter(g3):
+    n = 512
+    with rp.Batch(n) as b:
+        b.set_state(g3["init"][:n])
+        b.solve(1e-8, 3, 0)
+        it, status = b.get_iters()
+        assert np.all(it == 3) and np.all(status & rp.ST_MAXITER)
+        st3 = b.get_state()
+        b.solve(1e-8, 3, 0)                       # capped problems do not move again
+        assert np.array_equal(b.get_state(), st3)
+        b.set_state(g3["init"][:n])
+        b.solve(1e-8, 200, 0)
+        done = b.get_state()
+        b.solve(1e-8, 200, 0)                     # converged problems do not move again
+        assert np.array_equal(b.get_state(), done)
+        assert np.array_equal(b.get_iters()[0], g3["iters"][:n])
+
+
+# ---------------------------------------------------------------- live oracle on fresh seeds
+@pytest.mark.parametrize("dist", [rp.problems.DIST_MONOTONE, rp.problems.DIST_REFERENCE_LIKE, rp.problems.DIST_NON_MONOTONE])
+def test_gated_solve_against_live_oracle(oracle, dist):
+    n = 20000
+    p0, p1, p2 = rp.problems.generate(777, 0, n, dist)
+    aos = oracle.batch_init_feasible(3, p0, p1, p2)
+    it_o, total = oracle.batch_solve_gated(3, aos, 1e-8, 200)
+    with rp.Batch(n) as b:
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 200, 0)
+        it_g, status = b.get_iters()
+        st = b.get_state()
+    mism = int((it_g != it_o).sum())
+    assert mism == 0, "%d iteration-count mismatches" % mism
+    assert serr(st[:, :3], aos[:, :3]) < TOL
+    assert np.all(status == rp.ST_CONVERGED)
+
+
+# ---------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("n", [1, 63, 64, 255, 256, 257, 1000])
+def test_ragged_batch_sizes(oracle, n):
+    p0, p1, p2 = rp.problems.generate(5, 0, n, 0)
+    aos = oracle.batch_init_feasible(3, p0, p1, p2)
+    oracle.batch_steps(3, aos, 6)
+    with rp.Batch(n) as b:
+        b.set_problems(p0, p1, p2)
+        b.step(6)
+        assert serr(b.get_state()[:, :3], aos[:, :3]) < TOL
+
+
+def test_stuck_state_trajectory(traj, oracle):
+    with rp.Batch(3) as b:
+        b.init_stuck()
+        for s in range(1, 31):
+            b.step(1)
+            st = b.get_state()
+            assert np.array_equal(st[0], st[1]) and np.array_equal(st[0], st[2])
+            if s <= 12:
+                assert serr(st[0, :3], traj["stuck_states"][s, :3]) < 1e-8, s
+        # the method stalls here (initStuck, onedpath_ip.cpp:177-199): gap stays ~2.08
+        assert abs(oracle.gap(3, st[0]) - 2.077) < 5e-3
+
+
+def test_infeasible_start_is_frozen_and_flagged(traj):
+    with rp.Batch(2) as b:
+        b.init_default()
+        b.nudge(13, 150.0)           # pos1 200 -> 350: SURVEY.md 8c's infeasible start (Up key x15)
+        before = b.get_state()
+        assert np.array_equal(before[0, 11:], traj["infeasible_const"])
+        b.step(3)
+        after = b.get_state()
+        assert np.max(np.abs(after - before)) < 1e-25              # 100 halvings: s ~ 8e-31
+        assert serr(after[0, :11], traj["infeasible_states"][3]) < 1e-12
+        b.solve(1e-8, 5, 0)
+        _, status = b.get_iters()
+        assert np.all(status & rp.ST_INFEASIBLE) and np.all(status & rp.ST_MAXITER)
+
+
+def test_non_finite_input_is_flagged_not_fatal():
+    with rp.Batch(4) as b:
+        b.init_default()
+        st = b.get_state()
+        st[1, 1] = np.nan
+        st[2, 2] = 0.0            # division by a zero duration (unguarded in the reference too, onedpath_ip.cpp:385)
+        b.set_state(st)
+        b.solve(1e-8, 30, 0)
+        it, status = b.get_iters()
+        out = b.get_state()
+        assert status[0] == rp.ST_CONVERGED and status[3] == rp.ST_CONVERGED
+        assert np.array_equal(out[0], out[3])
+        assert status[1] & rp.ST_NONFINITE and status[1] & rp.ST_MAXITER and it[1] == 30
+
+
+def test_nudges_match_special_keys():
+    with rp.Batch(5) as b:
+        b.init_default()
+        b.nudge(1, 0.1); b.nudge(2, -0.1); b.nudge(0, 1.0); b.nudge(13, -10.0)
+        st = b.get_state()
+        assert np.allclose(st[:, 1], 3.6) and np.allclose(st[:, 2], 3.4) and np.all(st[:, 0] == 1.0) and np.all(st[:, 13] == 190.0)
+        with pytest.raises(rp.RpError):
+            b.nudge(16, 1.0)
+
+
+def test_params_change_behaviour_and_are_validated(oracle):
+    with rp.Batch(8) as b:
+        with pytest.raises(rp.RpError):
+            b.set_params(backtrack=1.5)
+        b.set_params(accel_limit=50.0)
+        assert b.get_params().accel_limit == 50.0
+        b.set_problems(np.zeros(8), np.full(8, 100.0), np.full(8, 250.0))
+        b.solve(1e-8, 200, 0)
+        st = b.get_state()
+        pos, acc = b.sample()
+        assert np.max(np.abs(acc)) <= 50.0 * (1 + 1e-9)             # the tighter limit binds
+        assert np.max(np.abs(acc)) > 49.99
+
+
+# ---------------------------------------------------------------- reduction
+def test_reduction_against_oracle(oracle, g3):
+    n = 3000
+    with rp.Batch(n) as b:
+        b.set_state(g3["init"][:n])
+        b.step(3)
+        st = b.get_state()
+        r = b.reduce()
+    gaps = np.array([oracle.gap(3, row) for row in st])
+    res = np.array([oracle.residual_norm(3, row, g / 80.0) for row, g in zip(st, gaps)])
+    assert abs(r["max_gap"] / gaps.max() - 1) < 1e-12
+    assert abs(r["max_residual_sq"] / res.max() - 1) < 1e-12
+    assert r["n_converged"] == 0 and r["total_steps"] == 3.0 * n
+
+
+# ---------------------------------------------------------------- F4
+def test_f4_fp64_single_steps(golden_dir):
+    t = np.load(os.path.join(golden_dir, "f4_steps.npz"))
+    n = len(t["state_in"])
+    with rp.Batch(n, variant=rp.VARIANT_F4, dtype=rp.DTYPE_F64) as b:
+        b.set_state(t["state_in"])
+        assert np.array_equal(b.get_state(), t["state_in"])
+        b.step(1)
+        st = b.get_state()
+    assert serr(st[:, :3], t["state_out"][:, :3]) < TOL
+    assert serr(st[:, 3:7], t["state_out"][:, 3:7]) < 1e-9
+
+
+def test_f4_fp32_single_steps(golden_dir):
+    # config 5: fp32; F4 trajectories are chaotic, so parity is per step from identical (fp32-exact) states
+    t = np.load(os.path.join(golden_dir, "f4_steps.npz"))
+    n = len(t["state_in"])
+    with rp.Batch(n, variant=rp.VARIANT_F4, dtype=rp.DTYPE_F32) as b:
+        b.set_state(t["state_in"])
+        assert np.array_equal(b.get_state(), t["state_in"])          # inputs are fp32-representable
+        b.step(1)
+        st = b.get_state()
+    err = np.abs(st[:, :3] - t["state_out"][:, :3]) / np.maximum(np.abs(t["state_out"][:, :3]), 1.0)
+    assert np.all(np.isfinite(st))
+    # fp32 tolerance: the step solves an ill-conditioned 3x3 system in single precision
+    assert np.median(err) < 1e-5
+    assert np.quantile(err, 0.99) < 2e-3
+
+
+def test_f4_default_trajectory(traj):
+    with rp.Batch(1, variant=rp.VARIANT_F4) as b:
+        b.init_default()
+        for s in range(1, 9):
+            b.step(1)
+            assert serr(b.get_state()[0, :3], traj["f4_default_states"][s, :3]) < 1e-9, s
+
+
+# ---------------------------------------------------------------- the rows either side of the path
+def test_sample_against_oracle(oracle, g3):
+    n = 500
+    with rp.Batch(n) as b:
+        b.set_state(g3["init"][:n])
+        b.step(5)
+        st = b.get_state()
+        pos, acc = b.sample()
+    for i in range(0, n, 7):
+        p, a = oracle.sample(3, st[i])
+        assert serr(pos[i], p) < 1e-13 and serr(acc[i], a) < 1e-13
+
+
+def test_move_toward_feasibility_against_oracle(oracle):
+    # starts with 1-3 violated constraints: durations too short and/or a large midpoint velocity
+    rng = np.random.RandomState(11)
+    n = 2000
+    p0, p1, p2 = rp.problems.generate(31, 0, n, 0)
+    aos = oracle.batch_init_feasible(3, p0, p1, p2)
+    aos[:, 1] *= rng.uniform(0.5, 1.2, n)
+    aos[:, 2] *= rng.uniform(0.5, 1.2, n)
+    aos[:, 0] = rng.uniform(-50, 250, n)
+    nviol = np.array([sum(oracle.constraint(3, i, row)[0] > 0 for i in range(8)) for row in aos])
+    with rp.Batch(n) as b:
+        b.set_state(aos)
+        b.move_toward_feasibility()
+        out = b.get_state()
+    exp = aos.copy()
+    for row in exp:
+        oracle.move_toward_feasibility(3, row)
+    full_rank = nviol <= 3
+    assert full_rank.sum() > 500 and (nviol > 0).sum() > 500
+    assert serr(out[full_rank, :3], exp[full_rank, :3]) < 1e-8
+    assert np.array_equal(out[nviol == 0], aos[nviol == 0])           # nothing violated: no move
+
+
+# ---------------------------------------------------------------- the C++ plug-in through the headless shell
+def test_headless_shell_reproduces_the_survey_kats(golden_dir):
+    import json
+    exe = os.path.join(ROOT, "rocket_path_amd", "lib", "rp_headless")
+    kat = json.load(open(os.path.join(golden_dir, "survey_kat.json")))["f3_default"]
+    out = subprocess.run([exe, "--n", "1", "--keys", "i n s n s n13 s"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    states = [list(map(float, l.split()[1:])) for l in out.stdout.splitlines() if l.startswith("State17:")]
+    assert len(states) == 3
+    assert serr(states[0], kat["after_step_1"]) < 1e-11
+    assert serr(states[1], kat["after_step_2"]) < 1e-11
+    assert serr(states[2][:3], kat["after_step_15_v_t0_t1"]) < 1e-12
+    assert "Node 1: pos=200" in out.stdout and "Duration 0:" in out.stdout
