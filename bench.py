@@ -41,6 +41,18 @@ B_ALG_F3 = 216.0          # bytes per problem per Newton step: read 16, write 11
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def cpu_quota():
+    """CPUs this process may really use: affinity mask capped by the cgroup v2 cpu.max quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(sample_n):
     """The oracle (C restatement of the reference's CPU step, own 11x11 QR) on the host cores.
     Reported baseline only -- never the thing measured above."""
@@ -48,7 +60,7 @@ def cpu_baseline(sample_n):
     from oracle_api import Oracle
     from rocket_path_amd import problems
     orc = Oracle()
-    threads = orc.hw_threads()
+    threads = min(orc.hw_threads(), cpu_quota())
     p0, p1, p2 = problems.generate(SEED, 0, sample_n, problems.DIST_MONOTONE)
     aos = orc.batch_init_feasible(3, p0, p1, p2)
     t0 = time.perf_counter()
