@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--problems-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="debug: run the N-rank code path with every rank on device 0 and gloo for the collectives "
+                         "(RCCL refuses two ranks on one GPU); numbers from such a run are not benchmark results")
     args = ap.parse_args()
 
     import torch
@@ -103,10 +106,17 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available() or rp.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback to time)")
+    rehearsal = args.rehearse_on_one_gpu
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n_total = args.problems_per_gpu * world
     first, count = problems.shard_range(n_total, rank, world)
@@ -133,7 +143,7 @@ def main():
     for b in batches[:W]:
         b.solve(GAP_TOL, MAX_ITER, 0)
     if world > 1:
-        sharding.allreduce_summary(summary.clone())     # RCCL communicator setup outside the timed region
+        sharding.allreduce_summary(summary.clone().to(coll_dev))     # RCCL communicator setup outside the timed region
     barrier()
 
     # ---- timed: exactly K passes, then the final summary reduction (+ all-reduce) ----
@@ -144,14 +154,14 @@ def main():
     lead.event_record(1)
     batches[-1].reduce_device(summary.data_ptr())
     lead.sync()
-    sharding.allreduce_summary(summary)
+    summary = sharding.allreduce_summary(summary.to(coll_dev))
     barrier()
     elapsed = time.perf_counter() - t0
 
     kernel_ms = lead.event_elapsed_ms(0, 1) / max(K, 1)
     steps_local = sum(b.reduce()["total_steps"] for b in batches[W:])
     conv_local = sum(b.reduce()["n_converged"] for b in batches[W:])
-    t = torch.tensor([elapsed, steps_local, conv_local], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    t = torch.tensor([elapsed, steps_local, conv_local], dtype=torch.float64, device=coll_dev)
     if world > 1:
         tm = t[:1].clone()
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -189,7 +199,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo collectives -- not a result)",
         "config": {
             "workload": "BASELINE configs[2] (C3): %d F3 onedpath_ip problems per GPU, convergence-gated "
                         "(surrogate gap < 1e-8 checked before every step, cap 200), fp64, monotone seeded positions, "

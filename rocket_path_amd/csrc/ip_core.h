@@ -17,14 +17,25 @@
 // feasibility backtracking, residual backtracking, the update -- is the reference's logic
 // decision for decision.
 //
+// F3's eight constraints are four (-a_j - L, a_j - L) pairs on the four end accelerations,
+// with opposite gradients and Hessians, so the assembly works per acceleration:
+//     S lam g      = (lp - lm) grad a          S lam H = (lp - lm) hess a
+//     S (lam/c) gg = (lm/cm + lp/cp) grad a grad a^T
+//     S g p/c      = p (1/cp - 1/cm) grad a
+// and 1/cm, 1/cp come from ONE reciprocal of cm*cp.
+//
 // Arithmetic notes (tolerance of the path is 1e-10 relative, not bitwise):
 //  * compiled with -ffp-contract=off; every fused multiply-add below is written out, so the
 //    same expression gives the same bits wherever it is inlined.  That is what makes the two
 //    memoisations exact: a trial point that is bitwise the current point re-uses the current
 //    point's evaluation (the reference recomputes the same numbers), and the evaluation at
 //    the accepted trial point is carried into the next step instead of being recomputed.
-//  * 1/t0 and 1/t1 are formed once per trial point (the reference divides by t about 20
-//    times per constraint sweep, onedpath_ip.cpp:385-391, 404-410).
+//  * the kernel is fp64-ALU bound, and an IEEE fp64 division costs 11 instructions on gfx950
+//    (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup).  Every division on the path is a
+//    reciprocal: v_rcp_f64 + two Newton iterations (5 instructions, <= 1-2 ulp), shared where
+//    the reference divides repeatedly by the same number (it divides by t about 20 times per
+//    constraint sweep, onedpath_ip.cpp:385-391, 404-410).  Define RP_EXACT_DIV to build with
+//    correctly rounded divisions instead (A/B builds for parity checks).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -43,21 +54,48 @@ template <typename T> __device__ __forceinline__ T sqrt_(T a);
 template <> __device__ __forceinline__ double sqrt_<double>(double a) { return __builtin_sqrt(a); }
 template <> __device__ __forceinline__ float sqrt_<float>(float a) { return __builtin_sqrtf(a); }
 
+template <typename T> __device__ __forceinline__ T min_(T a, T b);      // NaN in one operand -> the other
+template <> __device__ __forceinline__ double min_<double>(double a, double b) { return __builtin_fmin(a, b); }
+template <> __device__ __forceinline__ float min_<float>(float a, float b) { return __builtin_fminf(a, b); }
+
 template <typename T> __device__ __forceinline__ bool finite_(T a) { return abs_(a) <= T(1.7976931348623157e308) && a == a; }
 template <> __device__ __forceinline__ bool finite_<float>(float a) { return abs_(a) <= 3.4028234e38f && a == a; }
+
+// reciprocal
+template <typename T> __device__ __forceinline__ T rcp_(T x);
+#ifdef RP_EXACT_DIV
+template <> __device__ __forceinline__ double rcp_<double>(double x) { return 1.0 / x; }
+template <> __device__ __forceinline__ float rcp_<float>(float x) { return 1.0f / x; }
+#else
+template <> __device__ __forceinline__ double rcp_<double>(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+template <> __device__ __forceinline__ float rcp_<float>(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
+#endif
+// 1/den, or 0 for a zero denominator (rank-deficient pivot: that component of the step is 0)
+template <typename T> __device__ __forceinline__ T srcp_(T den) { return den != T(0) ? rcp_(den) : T(0); }
 
 // Solver constants in the compute type (rp_params, include/rp_batch.h).
 template <typename T> struct KParams {
     T limit;        // L
-    T mu_den;       // m * mu_divisor: perturbation = gap / mu_den   (onedpath_ip.cpp:812)
+    T inv_mu_den;   // 1 / (m * mu_divisor): perturbation = gap / (m * 10)   (onedpath_ip.cpp:812)
     T boundary;     // 0.99
     T backtrack;    // 0.5
     T armijo;       // 0.01
-    T c_floor;      // |c_i| below this is rounding noise of (a - L): condensed as -c_floor (see newton_step)
+    T c_floor;      // |c_i| below this is rounding noise of (a - L): condensed as -c_floor (see c_guard)
     int max_bt;     // 100
 };
 
-// The five per-problem constants (enum V 11..15) plus the two position deltas.
+// The per-problem constants the step needs (enum V 11..15 reduced to velocities and deltas).
 template <typename T> struct Prob {
     T v0, v2;      // vel0X, vel2X
     T dx0, dx1;    // pos1X - pos0X, pos2X - pos1X
@@ -70,8 +108,14 @@ template <typename T> struct Acc {
     T r0, r1;      // 1/t0, 1/t1
     T a[4];
     T gt[4];       // d a_j / d t_seg(j)
-    T gv[4];       // d a_j / d vel1
 };
+
+// d a_j / d vel1: dAdV1 of segment 0's ends (-2/t0, 4/t0), dAdV0 of segment 1's ends (-4/t1, 2/t1)
+// (onedpath_ip.cpp:390-391, 431-432).  Not stored: one multiply from the reciprocals.
+template <typename T> __device__ __forceinline__ T acc_gv(const Acc<T> &e, int j)
+{
+    return j == 0 ? T(-2) * e.r0 : j == 1 ? T(4) * e.r0 : j == 2 ? T(-4) * e.r1 : T(2) * e.r1;
+}
 
 template <int VARIANT> struct CMap;
 template <> struct CMap<3> { static constexpr int NC = 8; };   // onedpath_ip.cpp:101
@@ -81,7 +125,7 @@ template <> struct CMap<4> { static constexpr int NC = 4; };   // onedpath2_ip.c
 template <typename T>
 __device__ __forceinline__ void accel_values(const Prob<T> &k, T v, T t0, T t1, Acc<T> &e)
 {
-    const T r0 = T(1) / t0, r1 = T(1) / t1;
+    const T r0 = rcp_(t0), r1 = rcp_(t1);
     e.r0 = r0;
     e.r1 = r1;
     const T u0 = k.dx0 * r0, u1 = k.dx1 * r1;                 // dX / t
@@ -110,10 +154,6 @@ __device__ __forceinline__ void accel_grads(const Prob<T> &k, T v, Acc<T> &e)
     e.gt[1] = fma_(T(12), u0, -n0) * q0;
     e.gt[2] = fma_(T(-12), u1, -m1) * q1;
     e.gt[3] = fma_(T(12), u1, -n1) * q1;
-    e.gv[0] = T(-2) * r0;      // dAdV1 of the initial end, segment 0
-    e.gv[1] = T(4) * r0;       // dAdV1 of the final end
-    e.gv[2] = T(-4) * r1;      // dAdV0 of the initial end, segment 1
-    e.gv[3] = T(2) * r1;       // dAdV0 of the final end
 }
 
 // second derivatives (evalAccelSecondDerivInit / Final, onedpath_ip.cpp:394-411, 435-452)
@@ -159,10 +199,10 @@ __device__ __forceinline__ void c_grad(int i, const Acc<T> &e, T &gv, T &gt)
 {
     if constexpr (VARIANT == 3) {
         const int j = i >> 1;
-        gv = (i & 1) ? e.gv[j] : -e.gv[j];
+        gv = (i & 1) ? acc_gv(e, j) : -acc_gv(e, j);
         gt = (i & 1) ? e.gt[j] : -e.gt[j];
     } else {
-        gv = e.a[i] * e.gv[i];
+        gv = e.a[i] * acc_gv(e, i);
         gt = e.a[i] * e.gt[i];
     }
 }
@@ -172,13 +212,20 @@ template <int VARIANT> __device__ __forceinline__ constexpr int c_segment(int i)
     return VARIANT == 3 ? (i >> 2) : (i >> 1);
 }
 
-// constraintsSatisfied (onedpath_ip.cpp:738-751): false iff some error > 0 (NaN passes, as there)
+// constraintsSatisfied (onedpath_ip.cpp:738-751): false iff some error > 0 (NaN passes, as there).
+// F3: -a - L > 0 or a - L > 0  <=>  |a| > L exactly (a floating-point difference has the sign of
+// the exact difference), so one compare per acceleration.
 template <typename T, int VARIANT>
 __device__ __forceinline__ bool all_satisfied(const Acc<T> &e, T L)
 {
     bool ok = true;
+    if constexpr (VARIANT == 3) {
 #pragma unroll
-    for (int i = 0; i < CMap<VARIANT>::NC; ++i) ok = ok && !(c_value<T, VARIANT>(i, e, L) > T(0));
+        for (int j = 0; j < 4; ++j) ok = ok && !(abs_(e.a[j]) > L);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ok = ok && !(c_value<T, 4>(i, e, L) > T(0));
+    }
     return ok;
 }
 
@@ -192,20 +239,39 @@ __device__ __forceinline__ T duality_gap(const Acc<T> &e, const T (&lam)[CMap<VA
     return mu;
 }
 
-// residualNorm (onedpath_ip.cpp:753-792): || (grad f + G^T lam ; lam.c + p) ||^2
-template <typename T, int VARIANT>
-__device__ __forceinline__ T residual_norm(const Acc<T> &e, const T (&lam)[CMap<VARIANT>::NC], T p, T L)
+// residualNorm (onedpath_ip.cpp:753-792): || (grad f + G^T lam ; lam.c + p) ||^2, evaluated at the
+// multipliers lam + s*dl (TRIAL) or lam (not TRIAL; dl and s unused) without materialising them.
+template <typename T, int VARIANT, bool TRIAL>
+__device__ __forceinline__ T residual_norm(const Acc<T> &e, const T (&lam)[CMap<VARIANT>::NC],
+                                           const T (&dl)[CMap<VARIANT>::NC], T s, T p, T L)
 {
     T rv = T(0), rt0 = T(1), rt1 = T(1), acc = T(0);
+    if constexpr (VARIANT == 3) {
 #pragma unroll
-    for (int i = 0; i < CMap<VARIANT>::NC; ++i) {
-        T gv, gt;
-        c_grad<T, VARIANT>(i, e, gv, gt);
-        rv = fma_(lam[i], gv, rv);
-        if (c_segment<VARIANT>(i) == 0) rt0 = fma_(lam[i], gt, rt0);
-        else                            rt1 = fma_(lam[i], gt, rt1);
-        const T rc = fma_(lam[i], c_value<T, VARIANT>(i, e, L), p);
-        acc = fma_(rc, rc, acc);
+        for (int j = 0; j < 4; ++j) {
+            const T lm = TRIAL ? fma_(dl[2 * j], s, lam[2 * j]) : lam[2 * j];
+            const T lp = TRIAL ? fma_(dl[2 * j + 1], s, lam[2 * j + 1]) : lam[2 * j + 1];
+            const T d = lp - lm;
+            rv = fma_(d, acc_gv(e, j), rv);
+            if (j < 2) rt0 = fma_(d, e.gt[j], rt0);
+            else       rt1 = fma_(d, e.gt[j], rt1);
+            const T rm = fma_(lm, -e.a[j] - L, p);
+            const T rp = fma_(lp, e.a[j] - L, p);
+            acc = fma_(rm, rm, acc);
+            acc = fma_(rp, rp, acc);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T li = TRIAL ? fma_(dl[i], s, lam[i]) : lam[i];
+            T gv, gt;
+            c_grad<T, 4>(i, e, gv, gt);
+            rv = fma_(li, gv, rv);
+            if (i < 2) rt0 = fma_(li, gt, rt0);
+            else       rt1 = fma_(li, gt, rt1);
+            const T rc = fma_(li, c_value<T, 4>(i, e, L), p);
+            acc = fma_(rc, rc, acc);
+        }
     }
     acc = fma_(rv, rv, acc);
     acc = fma_(rt0, rt0, acc);
@@ -214,7 +280,9 @@ __device__ __forceinline__ T residual_norm(const Acc<T> &e, const T (&lam)[CMap<
 }
 
 // 3x3 solve, Gaussian elimination with partial pivoting (row of largest magnitude, first
-// wins ties), branch-free.  A is symmetric with A[1][2] = 0 on entry but is treated as general.
+// wins ties), branch-free, three reciprocals.  A zero pivot means a zero column: the
+// reference's rank-revealing QR sets that component of the step to 0
+// (ColPivHouseholderQR.h:609-610); srcp_ does the same here.
 template <typename T>
 __device__ __forceinline__ void swap_if(bool c, T &a, T &b)
 {
@@ -223,13 +291,10 @@ __device__ __forceinline__ void swap_if(bool c, T &a, T &b)
     b = tb;
 }
 
-template <typename T> __device__ __forceinline__ T sdiv(T num, T den) { return den != T(0) ? num / den : T(0); }
-
 template <typename T>
 __device__ __forceinline__ void solve3(T a00, T a01, T a02, T a10, T a11, T a12, T a20, T a21, T a22,
                                        T b0, T b1, T b2, T &x0, T &x1, T &x2)
 {
-    // column 0
     {
         const T m0 = abs_(a00), m1 = abs_(a10), m2 = abs_(a20);
         const bool s1 = (m1 > m0) && !(m2 > m1);      // row 1 is the pivot
@@ -237,117 +302,143 @@ __device__ __forceinline__ void solve3(T a00, T a01, T a02, T a10, T a11, T a12,
         swap_if(s1, a00, a10); swap_if(s1, a01, a11); swap_if(s1, a02, a12); swap_if(s1, b0, b1);
         swap_if(s2, a00, a20); swap_if(s2, a01, a21); swap_if(s2, a02, a22); swap_if(s2, b0, b2);
     }
-    // A zero pivot means a zero column: the reference's rank-revealing QR sets that component of
-    // the step to 0 (ColPivHouseholderQR.h:609-610); dividing "by zero -> 0" does the same here.
+    const T i0 = srcp_(a00);
     {
-        const T l1 = sdiv(a10, a00), l2 = sdiv(a20, a00);
+        const T l1 = a10 * i0, l2 = a20 * i0;
         a11 = fma_(-l1, a01, a11); a12 = fma_(-l1, a02, a12); b1 = fma_(-l1, b0, b1);
         a21 = fma_(-l2, a01, a21); a22 = fma_(-l2, a02, a22); b2 = fma_(-l2, b0, b2);
     }
-    // column 1
     {
         const bool s = abs_(a21) > abs_(a11);
         swap_if(s, a11, a21); swap_if(s, a12, a22); swap_if(s, b1, b2);
     }
+    const T i1 = srcp_(a11);
     {
-        const T l2 = sdiv(a21, a11);
+        const T l2 = a21 * i1;
         a22 = fma_(-l2, a12, a22); b2 = fma_(-l2, b1, b2);
     }
-    x2 = sdiv(b2, a22);
-    x1 = sdiv(fma_(-a12, x2, b1), a11);
-    x0 = sdiv(fma_(-a02, x2, fma_(-a01, x1, b0)), a00);
+    x2 = b2 * srcp_(a22);
+    x1 = fma_(-a12, x2, b1) * i1;
+    x0 = fma_(-a02, x2, fma_(-a01, x1, b0)) * i0;
+}
+
+// An active constraint converges to c_i = 0, sometimes exactly (the default problem ends at
+// a = L bit for bit).  The reference's 11x11 QR is indifferent to a zero on the diagonal; the
+// condensation divides by c_i, so values inside the rounding noise of (a - L) are condensed as
+// the negative number of that size: the reference row lam_i g_i.dx + c_i dlam_i = -(lam_i c_i + p)
+// is then solved with c_i perturbed by less than one ulp of L.
+template <typename T> __device__ __forceinline__ T c_guard(T c, T c_floor) { return (abs_(c) < c_floor) ? -c_floor : c; }
+
+// ---- the Newton direction (onedpath_ip.cpp:812-887, condensed) --------------------------
+// In: point (v; e = values + grads there), multipliers, perturbation p.  Out: dx, d lam.
+template <typename T, int VARIANT>
+__device__ __forceinline__ void direction(const Prob<T> &k, const KParams<T> &kp, T v, const T (&lam)[CMap<VARIANT>::NC],
+                                          const Acc<T> &e, T p, T &dxv, T &dx0, T &dx1, T (&dl)[CMap<VARIANT>::NC])
+{
+    const T L = kp.limit;
+    T htt[4], htv[4];
+    accel_hess(k, v, e, htt, htv);
+    T kvv = T(0), kv0 = T(0), kv1 = T(0), k00 = T(0), k11 = T(0);
+    T bv = T(0), b0 = T(-1), b1 = T(-1);
+
+    if constexpr (VARIANT == 3) {
+        T icm[4], icp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T lm = lam[2 * j], lp = lam[2 * j + 1];
+            const T cm = c_guard(-e.a[j] - L, kp.c_floor), cp = c_guard(e.a[j] - L, kp.c_floor);
+            const T ipr = rcp_(cm * cp);          // 1/cm = cp/(cm cp), 1/cp = cm/(cm cp)
+            icm[j] = cp * ipr;
+            icp[j] = cm * ipr;
+            const T w = fma_(lm, icm[j], lp * icp[j]);      // lm/cm + lp/cp
+            const T q = p * (icp[j] - icm[j]);              // rhs weight of grad a_j
+            const T d = lp - lm;
+            const T gv = acc_gv(e, j), gt = e.gt[j];
+            const T wgv = w * gv, wgt = w * gt;
+            kvv = fma_(-wgv, gv, kvv);
+            bv = fma_(gv, q, bv);
+            if (j < 2) {
+                kv0 = fma_(d, htv[j], fma_(-wgv, gt, kv0));
+                k00 = fma_(d, htt[j], fma_(-wgt, gt, k00));
+                b0 = fma_(gt, q, b0);
+            } else {
+                kv1 = fma_(d, htv[j], fma_(-wgv, gt, kv1));
+                k11 = fma_(d, htt[j], fma_(-wgt, gt, k11));
+                b1 = fma_(gt, q, b1);
+            }
+        }
+        solve3<T>(kvv, kv0, kv1, kv0, k00, T(0), kv1, T(0), k11, bv, b0, b1, dxv, dx0, dx1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T lm = lam[2 * j], lp = lam[2 * j + 1];
+            const T da = fma_(acc_gv(e, j), dxv, e.gt[j] * (j < 2 ? dx0 : dx1));
+            dl[2 * j] = fma_(icm[j], fma_(lm, da, -p), -lm);           // -lm + (lm da - p)/cm
+            dl[2 * j + 1] = fma_(-icp[j], fma_(lp, da, p), -lp);       // -lp - (lp da + p)/cp
+        }
+    } else {
+        T w[4], pc[4], gv[4], gt[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T a = e.a[i];
+            const T ic = rcp_(c_guard((a * a - L * L) * T(0.5), kp.c_floor * L));
+            gv[i] = a * acc_gv(e, i);
+            gt[i] = a * e.gt[i];
+            w[i] = lam[i] * ic;
+            pc[i] = p * ic;
+            // Hessian of (a^2 - L^2)/2: (t,t) and (t,v) entries only.  The reference never writes the
+            // (vel1X,vel1X) entry (dAdV)^2 (onedpath2_ip.cpp:446-448) -- reproduced: nothing on kvv here.
+            const T Htt = fma_(e.gt[i], e.gt[i], a * htt[i]);
+            const T Htv = fma_(e.gt[i], acc_gv(e, i), a * htv[i]);
+            const T wgv = w[i] * gv[i], wgt = w[i] * gt[i];
+            kvv = fma_(-wgv, gv[i], kvv);
+            bv = fma_(gv[i], pc[i], bv);
+            if (i < 2) {
+                kv0 = fma_(lam[i], Htv, fma_(-wgv, gt[i], kv0));
+                k00 = fma_(lam[i], Htt, fma_(-wgt, gt[i], k00));
+                b0 = fma_(gt[i], pc[i], b0);
+            } else {
+                kv1 = fma_(lam[i], Htv, fma_(-wgv, gt[i], kv1));
+                k11 = fma_(lam[i], Htt, fma_(-wgt, gt[i], k11));
+                b1 = fma_(gt[i], pc[i], b1);
+            }
+        }
+        solve3<T>(kvv, kv0, kv1, kv0, k00, T(0), kv1, T(0), k11, bv, b0, b1, dxv, dx0, dx1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T gdx = fma_(gv[i], dxv, gt[i] * (i < 2 ? dx0 : dx1));
+            dl[i] = fma_(-w[i], gdx, -(lam[i] + pc[i]));
+        }
+    }
 }
 
 // ---- one Newton step -------------------------------------------------------------------
-// In:  x = (v, t0, t1), lam, and e = values + grads at x.   Out: the same at the new point.
+// In:  x = (v, t0, t1), lam, e = values + grads at x, gap = surrogate duality gap at x.
+// Out: the same at the new point (the caller recomputes the gap from e).
 template <typename T, int VARIANT>
-__device__ __forceinline__ void newton_step(const Prob<T> &k, const KParams<T> &kp,
+__device__ __forceinline__ void newton_step(const Prob<T> &k, const KParams<T> &kp, T gap,
                                             T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], Acc<T> &e)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     const T L = kp.limit;
+    const T p = gap * kp.inv_mu_den;                      // onedpath_ip.cpp:812
+    const bool feasible_here = all_satisfied<T, VARIANT>(e, L);
 
-    // -- assemble (onedpath_ip.cpp:812-861, condensed) --
-    T htt[4], htv[4];
-    accel_hess(k, v, e, htt, htv);
-
-    T c[NC], gv[NC], gt[NC];
-    bool feasible_here = true;
-    T gap = T(0);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        c[i] = c_value<T, VARIANT>(i, e, L);
-        c_grad<T, VARIANT>(i, e, gv[i], gt[i]);
-        feasible_here = feasible_here && !(c[i] > T(0));
-        gap = fma_(-c[i], lam[i], gap);
-    }
-    const T p = gap / kp.mu_den;
-
-    T kvv = T(0), kv0 = T(0), kv1 = T(0), k00 = T(0), k11 = T(0);
-    T bv = T(0), b0 = T(-1), b1 = T(-1);
-    T w[NC], pc[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        // An active constraint converges to c_i = 0, sometimes exactly (the default problem ends at
-        // a = L bit for bit).  The reference's 11x11 QR is indifferent to a zero on the diagonal;
-        // the condensation divides by c_i, so values inside the rounding noise of (a - L) are
-        // condensed as the negative number of that size.  The reference row lam_i g_i.dx + c_i dlam_i
-        // = -(lam_i c_i + p) is then solved with c_i perturbed by less than one ulp of L.
-        const T cs = (abs_(c[i]) < kp.c_floor) ? -kp.c_floor : c[i];
-        const T ic = T(1) / cs;
-        w[i] = lam[i] * ic;
-        pc[i] = p * ic;
-        // Hessian of constraint i: (t,t) and (t,v) entries only; F4 leaves (v,v) at zero
-        // although d2/dv2 of a^2/2 is not (onedpath2_ip.cpp:446-448) -- reproduced.
-        T Htt, Htv;
-        if constexpr (VARIANT == 3) {
-            const int j = i >> 1;
-            Htt = (i & 1) ? htt[j] : -htt[j];
-            Htv = (i & 1) ? htv[j] : -htv[j];
-        } else {
-            Htt = fma_(e.gt[i], e.gt[i], e.a[i] * htt[i]);
-            Htv = fma_(e.gt[i], e.gv[i], e.a[i] * htv[i]);
-        }
-        const T wgv = w[i] * gv[i], wgt = w[i] * gt[i];
-        kvv = fma_(-wgv, gv[i], kvv);
-        bv = fma_(gv[i], pc[i], bv);
-        if (c_segment<VARIANT>(i) == 0) {
-            kv0 = fma_(lam[i], Htv, fma_(-wgv, gt[i], kv0));
-            k00 = fma_(lam[i], Htt, fma_(-wgt, gt[i], k00));
-            b0 = fma_(gt[i], pc[i], b0);
-        } else {
-            kv1 = fma_(lam[i], Htv, fma_(-wgv, gt[i], kv1));
-            k11 = fma_(lam[i], Htt, fma_(-wgt, gt[i], k11));
-            b1 = fma_(gt[i], pc[i], b1);
-        }
-    }
-
-    // -- solve K dx = rhs, recover d lam --
-    T dxv, dx0, dx1;
-    solve3<T>(kvv, kv0, kv1, kv0, k00, T(0), kv1, T(0), k11, bv, b0, b1, dxv, dx0, dx1);
-
-    T dl[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const T gdx = fma_(gv[i], dxv, gt[i] * (c_segment<VARIANT>(i) == 0 ? dx0 : dx1));
-        dl[i] = fma_(-w[i], gdx, -(lam[i] + pc[i]));
-    }
+    T dxv, dx0, dx1, dl[NC];
+    direction<T, VARIANT>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
 
     // -- fraction to the boundary on the multipliers (onedpath_ip.cpp:903-915) --
     T s = T(1);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-        if (dl[i] < T(0)) {
-            const T q = -lam[i] / dl[i];
-            s = (q < s) ? q : s;
-        }
+        const T q = (dl[i] < T(0)) ? -lam[i] * rcp_(dl[i]) : T(1);
+        s = min_(s, q);                                   // std::min(s, q): a NaN q leaves s
     }
     s *= kp.boundary;
 
     // -- backtrack until primal feasible (onedpath_ip.cpp:919-928) --
     Acc<T> et;                 // evaluation at the current trial point
     T tv = v, tt0 = t0, tt1 = t1;
-    bool et_valid = false;     // et holds accel values of (tv,tt0,tt1) == x + s*dx
+    bool et_valid = false;     // et holds the accelerations of (tv,tt0,tt1) == x + s*dx
     for (int it = 0; it < kp.max_bt; ++it) {
         tv = fma_(dxv, s, v);
         tt0 = fma_(dx0, s, t0);
@@ -367,30 +458,26 @@ __device__ __forceinline__ void newton_step(const Prob<T> &k, const KParams<T> &
     }
 
     // -- backtrack until the residual decreases (onedpath_ip.cpp:932-945) --
-    const T r0n = residual_norm<T, VARIANT>(e, lam, p, L);
-    T tl[NC];
+    const T r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);
     bool accepted_eval = false;    // et = values + grads at the point the loop broke on
     bool accepted_same = false;    // ... which is bitwise the current point
     for (int it = 0; it < kp.max_bt; ++it) {
         tv = fma_(dxv, s, v);
         tt0 = fma_(dx0, s, t0);
         tt1 = fma_(dx1, s, t1);
-        bool same_x = (tv == v && tt0 == t0 && tt1 == t1);
+        const bool same_x = (tv == v && tt0 == t0 && tt1 == t1);
         bool same_l = true;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            tl[i] = fma_(dl[i], s, lam[i]);
-            same_l = same_l && (tl[i] == lam[i]);
-        }
+        for (int i = 0; i < NC; ++i) same_l = same_l && (fma_(dl[i], s, lam[i]) == lam[i]);
         T rn;
         if (same_x && same_l) {
             rn = r0n;
         } else if (same_x) {
-            rn = residual_norm<T, VARIANT>(e, tl, p, L);
+            rn = residual_norm<T, VARIANT, true>(e, lam, dl, s, p, L);
         } else {
             if (!et_valid) accel_values(k, tv, tt0, tt1, et);
             accel_grads(k, tv, et);
-            rn = residual_norm<T, VARIANT>(et, tl, p, L);
+            rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
         }
         et_valid = false;
         if (rn <= r0n * (T(1) - kp.armijo * s)) {

@@ -36,7 +36,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 {
     KParams<T> kp;
     kp.limit = (T)hp.accel_limit;
-    kp.mu_den = (T)(num_constraints(variant) * hp.mu_divisor);
+    kp.inv_mu_den = (T)(1.0 / (num_constraints(variant) * hp.mu_divisor));
     kp.boundary = (T)hp.boundary_fraction;
     kp.backtrack = (T)hp.backtrack;
     kp.armijo = (T)hp.armijo;
@@ -51,8 +51,11 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 //   GATED = true  : before each step stop if gap < tol or the problem's step count reached
 //                   max_iter; problems already finished are skipped
 //                   without touching their state.
+#ifndef RP_NEWTON_WAVES
+#define RP_NEWTON_WAVES 2     // minimum waves per SIMD the register allocator must leave room for
+#endif
 template <typename T, int VARIANT, bool GATED>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
 k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
          int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters)
 {
@@ -93,12 +96,12 @@ k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
 
         bool done = false;
         for (int s = 0; s < k; ++s) {
+            const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
             if (GATED) {
-                const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
                 if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
                 if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; break; }
             }
-            newton_step<T, VARIANT>(pr, kp, v, t0, t1, lam, e);
+            newton_step<T, VARIANT>(pr, kp, gap, v, t0, t1, lam, e);
             ++it;
             ++steps_here;
         }
@@ -166,7 +169,7 @@ k_reduce_partial(const T *__restrict__ base, size_t stride, size_t n, KParams<T>
         accel_values(pr, v, f[1 * stride], f[2 * stride], e);
         accel_grads(pr, v, e);
         const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
-        const T rn = residual_norm<T, VARIANT>(e, lam, gap / kp.mu_den, kp.limit);
+        const T rn = residual_norm<T, VARIANT, false>(e, lam, lam, T(0), gap * kp.inv_mu_den, kp.limit);
         mr = any ? nan_max((double)rn, mr) : (double)rn;
         mg = any ? nan_max((double)gap, mg) : (double)gap;
         any = true;
