@@ -50,9 +50,17 @@ def timed(fn, tag, steps_of):
 
 timed(lambda b: b.solve(1e-8, 200, 0), "gated fused 1M", lambda b: b.reduce()["total_steps"])
 for b in batches:
+    b.init_default()
+timed(lambda b: b.solve(1e-8, 200, 0), "gated fused 1M identical", lambda b: b.reduce()["total_steps"])
+for b in batches:
+    b.set_problems(p0, p1, p2)
+for b in batches:
     b.set_problems(p0, p1, p2)
 timed(lambda b: b.step(1), "k=1 ungated 1M (step 1)", lambda b: N)
 timed(lambda b: b.step(1), "k=1 ungated 1M (step 2)", lambda b: N)
+if os.environ.get("RP_STREAM_PROBE"):
+    timed(lambda b: b.step(0), "k=0 probe (16 ld + 11 st)", lambda b: N)
+    timed(lambda b: b.step(0), "k=0 probe again", lambda b: N)
 for b in batches:
     b.set_problems(p0, p1, p2)
 timed(lambda b: b.step(12), "k=12 ungated 1M", lambda b: 12 * N)

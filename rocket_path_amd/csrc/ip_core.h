@@ -91,7 +91,7 @@ template <typename T> struct KParams {
     T boundary;     // 0.99
     T backtrack;    // 0.5
     T armijo;       // 0.01
-    T c_floor;      // |c_i| below this is rounding noise of (a - L): condensed as -c_floor (see c_guard)
+    T c_floor;      // L * eps / 256: the shift applied to every c_i before it is inverted (see c_guard)
     int max_bt;     // 100
 };
 
@@ -324,10 +324,34 @@ __device__ __forceinline__ void solve3(T a00, T a01, T a02, T a10, T a11, T a12,
 
 // An active constraint converges to c_i = 0, sometimes exactly (the default problem ends at
 // a = L bit for bit).  The reference's 11x11 QR is indifferent to a zero on the diagonal; the
-// condensation divides by c_i, so values inside the rounding noise of (a - L) are condensed as
-// the negative number of that size: the reference row lam_i g_i.dx + c_i dlam_i = -(lam_i c_i + p)
-// is then solved with c_i perturbed by less than one ulp of L.
-template <typename T> __device__ __forceinline__ T c_guard(T c, T c_floor) { return (abs_(c) < c_floor) ? -c_floor : c; }
+// condensation divides by c_i.  So every c_i is shifted by -c_floor = -L*eps/256 before it is
+// inverted: about 1/80 of the rounding error c_i = a - L already carries (half an ulp of L), it
+// cannot cancel c_i (values of a - L are multiples of ulp(L)/2 >> c_floor), and an exact zero
+// becomes the negative number of that size.  One add instead of a compare and two selects.
+template <typename T> __device__ __forceinline__ T c_guard(T c, T c_floor) { return c - c_floor; }
+
+// K dx = rhs for the arrow matrix K = [[a, b, c], [b, d, 0], [c, 0, e]] (K(t0,t1) is structurally
+// zero).  d and e are eliminated first when they pass the Bunch-Kaufman 1x1 pivot test
+// |pivot| >= alpha * |off-diagonal of its column|, alpha = (1 + sqrt 17)/8 -- bounded growth, the
+// symmetric counterpart of partial pivoting -- which they do in all but the early, indefinite
+// iterations; otherwise the general partial-pivot elimination runs.  The branch is per lane; a
+// wave pays for both paths only while one of its lanes is in the indefinite regime.
+template <typename T>
+__device__ __forceinline__ void solve_arrow(T a, T b, T c, T d, T e, T rv, T r0, T r1, T &xv, T &x0, T &x1)
+{
+    const T alpha = T(0.6403882032022076);
+    if (abs_(d) >= alpha * abs_(b) && abs_(e) >= alpha * abs_(c)) {
+        const T id = srcp_(d), ie = srcp_(e);
+        const T lb = b * id, lc = c * ie;
+        const T sc = fma_(-lb, b, fma_(-lc, c, a));          // Schur complement on vel1
+        const T rs = fma_(-lb, r0, fma_(-lc, r1, rv));
+        xv = rs * srcp_(sc);
+        x0 = fma_(-b, xv, r0) * id;
+        x1 = fma_(-c, xv, r1) * ie;
+    } else {
+        solve3<T>(a, b, c, b, d, T(0), c, T(0), e, rv, r0, r1, xv, x0, x1);
+    }
+}
 
 // ---- the Newton direction (onedpath_ip.cpp:812-887, condensed) --------------------------
 // In: point (v; e = values + grads there), multipliers, perturbation p.  Out: dx, d lam.
@@ -367,7 +391,7 @@ __device__ __forceinline__ void direction(const Prob<T> &k, const KParams<T> &kp
                 b1 = fma_(gt, q, b1);
             }
         }
-        solve3<T>(kvv, kv0, kv1, kv0, k00, T(0), kv1, T(0), k11, bv, b0, b1, dxv, dx0, dx1);
+        solve_arrow<T>(kvv, kv0, kv1, k00, k11, bv, b0, b1, dxv, dx0, dx1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const T lm = lam[2 * j], lp = lam[2 * j + 1];
@@ -402,7 +426,7 @@ __device__ __forceinline__ void direction(const Prob<T> &k, const KParams<T> &kp
                 b1 = fma_(gt[i], pc[i], b1);
             }
         }
-        solve3<T>(kvv, kv0, kv1, kv0, k00, T(0), kv1, T(0), k11, bv, b0, b1, dxv, dx0, dx1);
+        solve_arrow<T>(kvv, kv0, kv1, k00, k11, bv, b0, b1, dxv, dx0, dx1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const T gdx = fma_(gv[i], dxv, gt[i] * (i < 2 ? dx0 : dx1));
@@ -466,14 +490,12 @@ __device__ __forceinline__ void newton_step(const Prob<T> &k, const KParams<T> &
         tt0 = fma_(dx0, s, t0);
         tt1 = fma_(dx1, s, t1);
         const bool same_x = (tv == v && tt0 == t0 && tt1 == t1);
-        bool same_l = true;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) same_l = same_l && (fma_(dl[i], s, lam[i]) == lam[i]);
         T rn;
-        if (same_x && same_l) {
-            rn = r0n;
-        } else if (same_x) {
-            rn = residual_norm<T, VARIANT, true>(e, lam, dl, s, p, L);
+        if (same_x) {
+            bool same_l = true;     // only worth asking once the step no longer moves x (stalled regime)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) same_l = same_l && (fma_(dl[i], s, lam[i]) == lam[i]);
+            rn = same_l ? r0n : residual_norm<T, VARIANT, true>(e, lam, dl, s, p, L);
         } else {
             if (!et_valid) accel_values(k, tv, tt0, tt1, et);
             accel_grads(k, tv, et);

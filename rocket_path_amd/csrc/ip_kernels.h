@@ -19,6 +19,7 @@ struct BatchView {
     int dtype;             // 0 = f64, 1 = f32
     int32_t *iters;        // gated Newton steps taken per problem
     uint32_t *status;      // RP_ST_* bits per problem
+    uint16_t *order;       // scheduling permutation for the fused solve (k_order_tiles): tile-local indices
     unsigned long long *counters;   // [0] problems still active after the last gated launch, [1] gated steps executed
 };
 
@@ -34,6 +35,8 @@ inline int num_constraints(int variant) { return variant == 4 ? 4 : 8; }
 hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStream_t stream);
 // up to k gated steps per problem (k = max_iter gives the fused solve); zeroes counters[0] first.
 hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream);
+// the fused solve (every problem to its gate in one launch), tiled and ordered by expected step count
+hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, hipStream_t stream);
 // max ||r||^2, max gap, #converged, gated steps (+ host_steps) -> d_out4 (device); d_partials has 4 * 1024 doubles.
 hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_steps, double *d_partials,
                          double *d_out4, hipStream_t stream);
@@ -46,6 +49,8 @@ hipError_t launch_init_feasible(const BatchView &b, const HostParams &hp, const 
 hipError_t launch_init_const(const BatchView &b, const double *host_state /* state_len values */, hipStream_t stream);
 hipError_t launch_nudge(const BatchView &b, int field, double delta, hipStream_t stream);
 hipError_t launch_clear_progress(const BatchView &b, hipStream_t stream);
+// recompute the scheduling order from the positions currently in the batch
+hipError_t launch_order(const BatchView &b, hipStream_t stream);
 
 // the rows either side of the hot path
 hipError_t launch_move_toward_feasibility(const BatchView &b, const HostParams &hp, hipStream_t stream);

@@ -14,6 +14,8 @@
 // plain blockIdx -> problem-range map is already XCD-neutral.
 #include "ip_kernels.h"
 
+#include <cstdlib>
+
 #include "../../include/rp_batch.h"
 #include "feas_core.h"
 #include "ip_core.h"
@@ -54,6 +56,41 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 #ifndef RP_NEWTON_WAVES
 #define RP_NEWTON_WAVES 2     // minimum waves per SIMD the register allocator must leave room for
 #endif
+
+// The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
+template <typename T, int VARIANT, bool GATED>
+__device__ __forceinline__ void run_lane(const Prob<T> &pr, const KParams<T> &kp, int k, T tol, int max_iter,
+                                         T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
+                                         int &it, uint32_t &st, int &steps_here, bool &still_open)
+{
+    Acc<T> e;
+    accel_values(pr, v, t0, t1, e);
+    accel_grads(pr, v, e);
+
+    bool done = false;
+    for (int s = 0; s < k; ++s) {
+        const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
+        if (GATED) {
+            if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
+            if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; break; }
+        }
+        newton_step<T, VARIANT>(pr, kp, gap, v, t0, t1, lam, e);
+        ++it;
+        ++steps_here;
+    }
+    if (GATED) {
+        if (!done) {   // settle the status now so the host knows whether to launch again
+            const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
+            if (gap < tol) { st |= RP_ST_CONVERGED; done = true; }
+            else if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; }
+        }
+        st &= ~(RP_ST_NONFINITE | RP_ST_INFEASIBLE);
+        if (!(finite_(v) && finite_(t0) && finite_(t1))) st |= RP_ST_NONFINITE;
+        if (!all_satisfied<T, VARIANT>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
+        still_open = !done;
+    }
+}
+
 template <typename T, int VARIANT, bool GATED>
 __global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
 k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
@@ -89,37 +126,11 @@ k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
             pr.dx0 = p1 - p0;
             pr.dx1 = p2 - p1;
         }
-
-        Acc<T> e;
-        accel_values(pr, v, t0, t1, e);
-        accel_grads(pr, v, e);
-
-        bool done = false;
-        for (int s = 0; s < k; ++s) {
-            const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
-            if (GATED) {
-                if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
-                if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; break; }
-            }
-            newton_step<T, VARIANT>(pr, kp, gap, v, t0, t1, lam, e);
-            ++it;
-            ++steps_here;
-        }
-
+        run_lane<T, VARIANT, GATED>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
         if (GATED) {
-            if (!done) {   // settle the status now so the host knows whether to launch again
-                const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
-                if (gap < tol) { st |= RP_ST_CONVERGED; done = true; }
-                else if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; }
-            }
-            st &= ~(RP_ST_NONFINITE | RP_ST_INFEASIBLE);
-            if (!(finite_(v) && finite_(t0) && finite_(t1))) st |= RP_ST_NONFINITE;
-            if (!all_satisfied<T, VARIANT>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
             iters[i] = it;
             status[i] = st;
-            still_open = !done;
         }
-
         if (steps_here > 0) {
             f[0 * stride] = v;
             f[1 * stride] = t0;
@@ -136,6 +147,200 @@ k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
             if (open_mask) atomicAdd(&counters[0], (unsigned long long)__popcll(open_mask));
             if (steps_wave) atomicAdd(&counters[1], (unsigned long long)steps_wave);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The streaming form of the ungated step: k Newton steps per problem (k = 1 is "one launch per
+// press of 'n'"), where 216 B per problem per step really cross HBM.  With k small a lane's
+// life is load (~2 us of HBM latency) -> ~1.5 us of arithmetic -> store, and at 2 waves per SIMD
+// (the step needs ~190 VGPRs) nothing overlaps the two.  So the grid is sized to what is
+// resident (2 blocks per CU) and every lane walks the batch with stride gridDim.x * 256,
+// loading problem i + stride into a second register set before it computes problem i: the
+// next state streams in under the arithmetic of the current one.
+template <typename T, int NF> struct LaneState { T f[NF]; };
+
+template <typename T, int VARIANT>
+__global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
+k_newton_stream(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    constexpr int CB = 3 + NC;
+    constexpr int NF = CB + 5;
+    const size_t step = (size_t)gridDim.x * kBlock;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    LaneState<T, NF> cur, nxt;
+    if (i >= n) return;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cur.f[f] = base[(size_t)f * stride + i];
+    for (;;) {
+        // The prefetch is unconditional (the last round re-reads its own problem): a conditional
+        // load makes the compiler's s_waitcnt pass assume the worst at the join and drain the
+        // queue (vmcnt(0)) before the arithmetic, which is exactly the overlap this kernel is for.
+        const size_t inext = i + step;
+        const bool have_next = inext < n;
+        const size_t src = have_next ? inext : i;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) nxt.f[f] = base[(size_t)f * stride + src];
+        T v = cur.f[0], t0 = cur.f[1], t1 = cur.f[2];
+        T lam[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) lam[c] = cur.f[3 + c];
+        Prob<T> pr;
+        pr.v0 = cur.f[CB + 1];
+        pr.v2 = cur.f[CB + 4];
+        pr.dx0 = cur.f[CB + 2] - cur.f[CB + 0];
+        pr.dx1 = cur.f[CB + 3] - cur.f[CB + 2];
+        int it = 0, steps_here = 0;
+        uint32_t st = 0;
+        bool still_open = false;
+        run_lane<T, VARIANT, false>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        T *f = base + i;
+        f[0 * stride] = v;
+        f[1 * stride] = t0;
+        f[2 * stride] = t1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = lam[c];
+        if (!have_next) break;
+        cur = nxt;
+        i = inext;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The fused gated solve, tiled and scheduled.  A wave runs until its slowest lane has
+// converged, and gated step counts differ from problem to problem (12-20 on the benchmark
+// distribution; problems whose two segments have similar length take longest), so in batch
+// order ~20 % of the lane-steps of a fused solve are idle.
+//
+// k_order_tiles (run when positions are set, not per solve) computes for every tile of 512
+// consecutive problems a permutation of the tile ordered by the segment-length ratio
+// min|dX|/max|dX| (64-bucket counting sort in LDS).  k_solve_tiled gives each 256-thread block
+// one tile: it stages the tile's 16 fields in LDS (64 KiB, coalesced both ways -- the
+// permutation never touches global addresses), and wave w solves sorted chunks w and 7-w, so
+// the 64 lanes of a wave hold problems of similar expected length and the four waves finish
+// together.  Idle lane-steps drop to ~5 %.  Which lane solves which problem changes nothing
+// in any problem's result (lanes never interact); a stale order (positions nudged after it
+// was computed) is merely a less effective schedule.
+constexpr int kTile = 512;
+constexpr int kBuckets = 64;
+
+template <typename T, int VARIANT>
+__global__ void __launch_bounds__(kBlock)
+k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__restrict__ order)
+{
+    constexpr int CB = 3 + CMap<VARIANT>::NC;
+    constexpr int PER = kTile / kBlock;
+    __shared__ unsigned s_hist[kBuckets], s_start[kBuckets], s_fill[kBuckets];
+    const int tid = threadIdx.x;
+    const size_t first = (size_t)blockIdx.x * kTile;
+    const int count = (n - first < (size_t)kTile) ? (int)(n - first) : kTile;
+    if (tid < kBuckets) { s_hist[tid] = 0; s_fill[tid] = 0; }
+    __syncthreads();
+    int key[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int j = tid + q * kBlock;
+        key[q] = -1;
+        if (j < count) {
+            const T p0 = base[(size_t)(CB + 0) * stride + first + j], p1 = base[(size_t)(CB + 2) * stride + first + j];
+            const T p2 = base[(size_t)(CB + 3) * stride + first + j];
+            const T d0 = abs_(p1 - p0), d1 = abs_(p2 - p1);
+            const T lo = d0 < d1 ? d0 : d1, hi = d0 < d1 ? d1 : d0;
+            const T r = lo / hi * T(kBuckets);
+            key[q] = (r >= T(0) && r < T(kBuckets)) ? (int)r : kBuckets - 1;   // equal lengths / NaN -> last bucket
+            atomicAdd(&s_hist[key[q]], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned acc = 0;
+        for (int b = 0; b < kBuckets; ++b) { s_start[b] = acc; acc += s_hist[b]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        if (key[q] >= 0) {
+            const unsigned pos = s_start[key[q]] + atomicAdd(&s_fill[key[q]], 1u);
+            order[first + pos] = (uint16_t)(tid + q * kBlock);      // tile-local index
+        }
+    }
+}
+
+template <typename T, int VARIANT>
+__global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
+k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T tol, int max_iter,
+              int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
+              const uint16_t *__restrict__ order)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    constexpr int CB = 3 + NC;
+    constexpr int NF = CB + 5;
+    __shared__ T sm[NF][kTile];
+    __shared__ int32_t s_it[kTile];
+    __shared__ uint32_t s_st[kTile];
+
+    const int tid = threadIdx.x;
+    const size_t first = (size_t)blockIdx.x * kTile;
+    const int count = (n - first < (size_t)kTile) ? (int)(n - first) : kTile;
+
+    // -- stage the tile: field-major in LDS, every global access a full coalesced segment
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+        for (int j = tid; j < count; j += kBlock) sm[f][j] = base[(size_t)f * stride + first + j];
+    for (int j = tid; j < count; j += kBlock) { s_it[j] = iters[first + j]; s_st[j] = status[first + j]; }
+    // this thread's two scheduled problems: sorted chunks `wave` and `7 - wave`
+    const int wave = tid >> 6, lane = tid & 63;
+    int mine[2];
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int slot = (round == 0 ? wave : (kTile / 64 - 1 - wave)) * 64 + lane;
+        mine[round] = slot < count ? (int)order[first + slot] : -1;
+    }
+    __syncthreads();
+
+    int steps_here = 0;
+    bool open_any = false;
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+        const int j = mine[round];
+        if (j >= 0 && (s_st[j] & (RP_ST_CONVERGED | RP_ST_MAXITER)) == 0) {
+            T v = sm[0][j], t0 = sm[1][j], t1 = sm[2][j];
+            T lam[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) lam[c] = sm[3 + c][j];
+            Prob<T> pr;
+            pr.v0 = sm[CB + 1][j];
+            pr.v2 = sm[CB + 4][j];
+            pr.dx0 = sm[CB + 2][j] - sm[CB + 0][j];
+            pr.dx1 = sm[CB + 3][j] - sm[CB + 2][j];
+            int it = s_it[j];
+            uint32_t st = s_st[j];
+            bool still_open = false;
+            run_lane<T, VARIANT, true>(pr, kp, max_iter > 0 ? max_iter : 1, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+            open_any = open_any || still_open;
+            sm[0][j] = v;
+            sm[1][j] = t0;
+            sm[2][j] = t1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sm[3 + c][j] = lam[c];
+            s_it[j] = it;
+            s_st[j] = st;
+        }
+    }
+    __syncthreads();
+
+    // -- write the tile back: mutable fields and progress words
+#pragma unroll
+    for (int f = 0; f < CB; ++f)
+        for (int j = tid; j < count; j += kBlock) base[(size_t)f * stride + first + j] = sm[f][j];
+    for (int j = tid; j < count; j += kBlock) { iters[first + j] = s_it[j]; status[first + j] = s_st[j]; }
+
+    const unsigned long long open_mask = __ballot(open_any);
+    const int steps_wave = wave_sum<int>(steps_here);
+    if (lane == 0) {
+        if (open_mask) atomicAdd(&counters[0], (unsigned long long)__popcll(open_mask));
+        if (steps_wave) atomicAdd(&counters[1], (unsigned long long)steps_wave);
     }
 }
 
@@ -399,10 +604,41 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
 
 hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStream_t stream)
 {
-    if (k <= 0 || b.n == 0) return hipSuccess;
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_newton<T, V, false>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                       (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), T(0), 0,
-                                       (int32_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr));
+    if (k < 0 || b.n == 0) return hipSuccess;     // k == 0: load/store only (bandwidth probe, see rp_batch_step)
+    // resident set: 256 CUs x 2 blocks (2 waves per SIMD); larger batches are walked with that stride
+    unsigned grid = grid_for(b.n);
+    if (grid > 512u) grid = 512u;
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_newton_stream<T, V>), dim3(grid), dim3(kBlock), 0, stream,
+                                       (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
+    return hipGetLastError();
+}
+
+hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(1), 0, stream, b.counters);
+    // Below ~2 tiles per CU slot the tiled kernel cannot fill the chip (one 256-thread block per
+    // 512 problems): small batches take the plain one-problem-per-lane kernel.
+    static const bool no_tiled = getenv("RP_NO_TILED") != nullptr;     // A/B switch for tuning
+    if (no_tiled || b.n < (size_t)kTile * 512) {
+        RP_DISPATCH(b, hipLaunchKernelGGL((k_newton<T, V, true>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                           (T *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
+                                           (T)gap_tol, max_iter, b.iters, b.status, b.counters));
+        return hipGetLastError();
+    }
+    const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_tiled<T, V>), dim3(grid), dim3(kBlock), 0, stream,
+                                       (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
+                                       b.iters, b.status, b.counters, (const uint16_t *)b.order));
+    return hipGetLastError();
+}
+
+hipError_t launch_order(const BatchView &b, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_order_tiles<T, V>), dim3(grid), dim3(kBlock), 0, stream,
+                                       (const T *)b.base, b.stride, b.n, b.order));
     return hipGetLastError();
 }
 

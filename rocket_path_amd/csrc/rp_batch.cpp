@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -72,6 +73,7 @@ int reset_progress(rp_batch *b)
 {
     b->ungated_steps = 0.0;
     RP_HIP(rp::launch_clear_progress(b->view, b->stream));
+    RP_HIP(rp::launch_order(b->view, b->stream));     // every init path ends here: positions are final
     return RP_OK;
 }
 
@@ -155,10 +157,12 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     if (e == hipSuccess) e = hipMalloc(&b->view.base, fields * b->view.stride * elem_size(dtype));
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.iters, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.status, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->view.order, n * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.counters, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_scratch, (4096 + 4) * sizeof(double));
     if (e == hipSuccess) e = hipMemsetAsync(b->view.base, 0, fields * b->view.stride * elem_size(dtype), b->stream);
     if (e == hipSuccess) e = rp::launch_clear_progress(b->view, b->stream);
+    if (e == hipSuccess) e = rp::launch_order(b->view, b->stream);
     if (e != hipSuccess) {
         const int code = fail(e == hipErrorOutOfMemory ? RP_ERR_NOMEM : RP_ERR_DEVICE, "rp_batch_create: %s", hipGetErrorString(e));
         rp_batch_destroy(b);
@@ -177,6 +181,7 @@ int rp_batch_destroy(rp_batch *b)
     if (b->view.base) (void)hipFree(b->view.base);
     if (b->view.iters) (void)hipFree(b->view.iters);
     if (b->view.status) (void)hipFree(b->view.status);
+    if (b->view.order) (void)hipFree(b->view.order);
     if (b->view.counters) (void)hipFree(b->view.counters);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
     if (b->d_aos) (void)hipFree(b->d_aos);
@@ -319,7 +324,9 @@ int rp_batch_step(rp_batch *b, int k)
 {
     RP_NEED(b);
     if (k < 0) return fail(RP_ERR_INVALID, "negative step count");
-    if (k == 0) return RP_OK;
+    // k == 0 is a no-op, except under RP_STREAM_PROBE=1 where it launches the step kernel with no
+    // steps: the same 16 loads and 11 stores per problem and nothing else (bandwidth calibration).
+    if (k == 0 && !getenv("RP_STREAM_PROBE")) return RP_OK;
     RP_HIP(rp::launch_steps(b->view, b->params, k, b->stream));
     b->ungated_steps += (double)k;
     return RP_OK;
@@ -331,7 +338,7 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
     if (max_iter < 0) return fail(RP_ERR_INVALID, "negative max_iter");
     if (!(gap_tol == gap_tol)) return fail(RP_ERR_INVALID, "gap_tol is NaN");
     if (steps_per_launch <= 0) {
-        RP_HIP(rp::launch_solve(b->view, b->params, max_iter > 0 ? max_iter : 1, gap_tol, max_iter, b->stream));
+        RP_HIP(rp::launch_solve_fused(b->view, b->params, gap_tol, max_iter, b->stream));
         return RP_OK;
     }
     // bounded host loop: every launch either finishes a problem or advances it by >= 1 step
