@@ -81,6 +81,20 @@ template <> __device__ __forceinline__ float rcp_<float>(float x)
     return r;
 }
 #endif
+// One refinement: <= 10 ulp (measured on gfx950: raw v_rcp_f64 is 2^-24, one Newton step 2.2e-15, two
+// steps bit-equal to IEEE 1/x on 4M samples -- profiles/probes/rcp_probe.hip).  Used only where the
+// quotient feeds a bound, not the iterate: the fraction-to-boundary ratios.
+template <typename T> __device__ __forceinline__ T rcp1_(T x);
+#ifdef RP_EXACT_DIV
+template <> __device__ __forceinline__ double rcp1_<double>(double x) { return 1.0 / x; }
+#else
+template <> __device__ __forceinline__ double rcp1_<double>(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+#endif
+template <> __device__ __forceinline__ float rcp1_<float>(float x) { return rcp_<float>(x); }
 // 1/den, or 0 for a zero denominator (rank-deficient pivot: that component of the step is 0)
 template <typename T> __device__ __forceinline__ T srcp_(T den) { return den != T(0) ? rcp_(den) : T(0); }
 
@@ -454,7 +468,7 @@ __device__ __forceinline__ void newton_step(const Prob<T> &k, const KParams<T> &
     T s = T(1);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-        const T q = (dl[i] < T(0)) ? -lam[i] * rcp_(dl[i]) : T(1);
+        const T q = (dl[i] < T(0)) ? -lam[i] * rcp1_(dl[i]) : T(1);
         s = min_(s, q);                                   // std::min(s, q): a NaN q leaves s
     }
     s *= kp.boundary;

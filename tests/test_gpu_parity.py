@@ -339,3 +339,57 @@ def test_headless_shell_reproduces_the_survey_kats(golden_dir):
     assert serr(states[1], kat["after_step_2"]) < 1e-11
     assert serr(states[2][:3], kat["after_step_15_v_t0_t1"]) < 1e-12
     assert "Node 1: pos=200" in out.stdout and "Duration 0:" in out.stdout
+
+
+# ---------------------------------------------------------------- the tiled fused solve (n >= 262,144)
+def test_tiled_solve_ragged_tail_and_resume(oracle):
+    # 512 full tiles + a 333-problem tail: the tiled kernel, its scheduling order and the ragged last tile
+    n = 512 * 512 + 333
+    p0, p1, p2 = rp.problems.generate(4242, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0, p1, p2)
+        a.solve(1e-8, 200, 0)            # fused: tiled, scheduled
+        b.solve(1e-8, 200, 7)            # plain kernel, 7 steps per launch
+        sa, sb = a.get_state(), b.get_state()
+        ia, ta = a.get_iters()
+        ib, tb = b.get_iters()
+        assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(ta, tb)   # schedule changes nothing
+        assert a.reduce()["total_steps"] == float(ia.sum())
+        # resume: a capped solve continued later equals the uninterrupted one
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 9, 0)
+        i9, t9 = b.get_iters()
+        assert np.all(i9 == 9) and np.all(t9 & rp.ST_MAXITER)
+    for sl in (slice(0, 4096), slice(n - 4096, n)):
+        aos = oracle.batch_init_feasible(3, p0[sl], p1[sl], p2[sl])
+        it_o, _ = oracle.batch_solve_gated(3, aos, 1e-8, 200)
+        assert np.array_equal(ia[sl], it_o)
+        assert serr(sa[sl, :3], aos[:, :3]) < TOL
+
+
+def test_tiled_solve_survives_a_stale_order():
+    # nudging positions after the order was computed only makes the schedule less effective
+    n = 512 * 512
+    p0, p1, p2 = rp.problems.generate(99, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        a.nudge(13, 10.0)                 # Up key: pos1 += 10 for every problem, order now stale
+        st = a.get_state()
+        b.set_state(st)                   # same state, fresh order
+        a.solve(1e-8, 200, 0)
+        b.solve(1e-8, 200, 0)
+        assert np.array_equal(a.get_state(), b.get_state())
+        assert np.array_equal(a.get_iters()[0], b.get_iters()[0])
+
+
+def test_tiled_solve_f4_fp32_matches_plain_kernel():
+    n = 512 * 512 + 5
+    p0, p1, p2 = rp.problems.generate(5, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32) as a, rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0, p1, p2)
+        a.solve(1e-3, 25, 0)
+        b.solve(1e-3, 25, 5)
+        assert np.array_equal(a.get_state(), b.get_state())
+        assert np.array_equal(a.get_iters()[0], b.get_iters()[0])
