@@ -18,9 +18,10 @@ N > 1: one process per GPU, rank r owns the contiguous shard r of the N x 1,048,
 all-reduce over RCCL.
 
 Printed by rank 0: ONE JSON line (contract in the task statement), with `roofline` for the
-dominant kernel (k_newton<double,3,gated>), `cpu_baseline` (oracle port, N = 1 only) and two
+dominant kernel (k_solve_tiled<double,3>), `cpu_baseline` (oracle port, N = 1 only) and three
 labelled extras: `per_step_launch` (the same step as one launch per Newton step, which is the
-HBM-streaming form: 216 B really cross HBM per step) and `fixed50` (configs[1]).
+HBM-streaming form: 216 B really cross HBM per step), `fixed50` (configs[1]) and `f4_fp32`
+(configs[4]).
 """
 import argparse
 import json
@@ -184,7 +185,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_newton_f3_f64_gated", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("k_solve_tiled_f3_f64", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     line = {
@@ -214,7 +215,7 @@ def main():
                         else "single GPU",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_newton<double, F3, gated> (fused: state stays in VGPRs between steps)",
+            "bound": "hbm", "kernel": "k_solve_tiled<double, F3> (fused gated solve: state stays in VGPRs between steps)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": B_ALG_F3 * steps_per_launch,
@@ -226,24 +227,52 @@ def main():
     }
 
     if not args.no_extras:
-        # (a) one launch per Newton step on never-touched batches: the HBM-streaming form of the same step
+        # (a) one launch per Newton step: the HBM-streaming form of the same step (216 B really move per step).
+        #     cold = every launch on a batch not touched since its init (state comes from HBM);
+        #     warm = the same 128 MiB batch stepped again and again (state stays in the 256 MiB Infinity Cache);
+        #     probe = the same kernel with zero steps: its 16 loads + 11 stores per problem and nothing else,
+        #             i.e. what this access pattern can reach on this box (the kernel's own ceiling).
         spare = batches[W:]
-        for b in spare:
-            b.set_problems_device(*ptrs)
-        lead.sync()
-        torch.cuda.synchronize()
+
+        def reinit():
+            for b in spare:
+                b.set_problems_device(*ptrs)
+            lead.sync()
+            torch.cuda.synchronize()
+
+        def sweep(fn):
+            lead.event_record(2)
+            for b in spare:
+                fn(b)
+            lead.event_record(3)
+            lead.sync()
+            return lead.event_elapsed_ms(2, 3) / len(spare)
+
+        reinit()
+        ms_cold = sweep(lambda b: b.step(1))
+        os.environ["RP_STREAM_PROBE"] = "1"
+        reinit()
+        ms_probe = sweep(lambda b: b.step(0))
+        del os.environ["RP_STREAM_PROBE"]
+        lead.set_problems_device(*ptrs)
+        lead.step(1)
         lead.event_record(2)
-        for b in spare:
-            b.step(1)
+        for _ in range(len(spare)):
+            lead.step(1)
         lead.event_record(3)
         lead.sync()
-        ms1 = lead.event_elapsed_ms(2, 3) / len(spare)
-        gbs = B_ALG_F3 * count / (ms1 * 1e-3) / 1e9
-        line["per_step_launch"] = {"kernel": "k_newton<double, F3, ungated>, k = 1", "avg_launch_ms": ms1,
-                                   "newton_steps_per_s": count / (ms1 * 1e-3), "achieved_GBps": gbs,
-                                   "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "launches": len(spare)}
+        ms_warm = lead.event_elapsed_ms(2, 3) / len(spare)
+        gbs = lambda ms: B_ALG_F3 * count / (ms * 1e-3) / 1e9   # noqa: E731
+        line["per_step_launch"] = {
+            "kernel": "k_newton_stream<double, F3>, k = 1 (register-prefetched, grid = resident set)",
+            "avg_launch_ms": ms_cold, "newton_steps_per_s": count / (ms_cold * 1e-3),
+            "achieved_GBps": gbs(ms_cold), "frac_of_hbm_peak": gbs(ms_cold) / HBM_PEAK_GBS,
+            "same_access_pattern_without_arithmetic_GBps": gbs(ms_probe),
+            "frac_of_that_ceiling": ms_probe / ms_cold,
+            "infinity_cache_resident_GBps": gbs(ms_warm),
+            "launches": len(spare)}
         # (b) configs[1]: 65,536 problems, exactly 50 steps each, one fused launch
-        n2 = 65536
+        n2 = min(65536, count)
         with rp.Batch(n2, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) as c2:
             ms = []
             for _ in range(4):
@@ -254,8 +283,32 @@ def main():
                 c2.event_record(5)
                 c2.sync()
                 ms.append(c2.event_elapsed_ms(4, 5))
-        line["fixed50"] = {"workload": "BASELINE configs[1] (C2): 65,536 problems x exactly 50 steps, one fused launch",
+        line["fixed50"] = {"workload": "BASELINE configs[1] (C2): 65,536 problems x exactly 50 steps, one fused launch "
+                                       "(about 35 of the 50 steps per problem run in the reference's post-convergence regime: "
+                                       "~48 residual halvings per step)",
                            "ms": min(ms[1:]), "newton_steps_per_s": n2 * 50 / (min(ms[1:]) * 1e-3)}
+        # (c) configs[4]: F4, fp32, 1,048,576 problems x 50 steps (76 B algorithmic per step)
+        with rp.Batch(count, rp.VARIANT_F4, rp.DTYPE_F32, device=local_rank, stream=stream) as c5:
+            ms50, ms1 = [], []
+            for _ in range(3):
+                c5.set_problems_device(*ptrs)
+                c5.sync()
+                c5.event_record(4)
+                c5.step(50)
+                c5.event_record(5)
+                c5.sync()
+                ms50.append(c5.event_elapsed_ms(4, 5))
+            for _ in range(3):
+                c5.set_problems_device(*ptrs)
+                c5.sync()
+                c5.event_record(4)
+                c5.step(1)
+                c5.event_record(5)
+                c5.sync()
+                ms1.append(c5.event_elapsed_ms(4, 5))
+        line["f4_fp32"] = {"workload": "BASELINE configs[4] (C5): F4 onedpath2_ip, fp32, %d problems" % count,
+                           "fused_50_steps_ms": min(ms50), "newton_steps_per_s": count * 50 / (min(ms50) * 1e-3),
+                           "k1_launch_ms": min(ms1), "k1_achieved_GBps": 76.0 * count / (min(ms1) * 1e-3) / 1e9}
 
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(count, 1 << 19))
