@@ -195,7 +195,8 @@ int rp_batch_set_params(rp_batch *b, const rp_params *p)
 {
     if (!b || !p) return fail(RP_ERR_INVALID, "null argument");
     if (!(p->accel_limit > 0) || !(p->mu_divisor > 0) || !(p->boundary_fraction > 0 && p->boundary_fraction <= 1) ||
-        !(p->backtrack > 0 && p->backtrack < 1) || !(p->armijo >= 0 && p->armijo < 1) || p->max_backtracks < 0)
+        !(p->backtrack > 0 && p->backtrack < 1) || !(p->armijo >= 0 && p->armijo < 1) || p->max_backtracks < 0 ||
+        p->max_backtracks > 4096)      // every device loop must stay short: a runaway kernel takes the GPU with it
         return fail(RP_ERR_INVALID, "parameter out of range");
     b->params.accel_limit = p->accel_limit;
     b->params.mu_divisor = p->mu_divisor;
@@ -323,7 +324,7 @@ int rp_batch_nudge(rp_batch *b, int var_index, double delta)
 int rp_batch_step(rp_batch *b, int k)
 {
     RP_NEED(b);
-    if (k < 0) return fail(RP_ERR_INVALID, "negative step count");
+    if (k < 0 || k > 1000000) return fail(RP_ERR_INVALID, "step count %d out of range (0..1000000)", k);
     // k == 0 is a no-op, except under RP_STREAM_PROBE=1 where it launches the step kernel with no
     // steps: the same 16 loads and 11 stores per problem and nothing else (bandwidth calibration).
     if (k == 0 && !getenv("RP_STREAM_PROBE")) return RP_OK;
@@ -335,7 +336,7 @@ int rp_batch_step(rp_batch *b, int k)
 int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_launch)
 {
     RP_NEED(b);
-    if (max_iter < 0) return fail(RP_ERR_INVALID, "negative max_iter");
+    if (max_iter < 0 || max_iter > 1000000) return fail(RP_ERR_INVALID, "max_iter %d out of range (0..1000000)", max_iter);
     if (!(gap_tol == gap_tol)) return fail(RP_ERR_INVALID, "gap_tol is NaN");
     if (steps_per_launch <= 0) {
         RP_HIP(rp::launch_solve_fused(b->view, b->params, gap_tol, max_iter, b->stream));
