@@ -8,10 +8,15 @@
 // 256 B (f32) segment.  One Newton step reads 16 and writes 11 fields (F3): 216 B per
 // problem per step, the algorithmic traffic the roofline is priced against.
 //
-// Launch shape: 256-thread blocks (4 waves), one problem per lane, grid = ceil(n / 256).
-// At n = 1 Mi that is 4096 blocks, 16 per CU, dealt round-robin over the 8 XCDs; problems
-// are independent and nothing is re-read, so there is no L2 locality to arrange and the
-// plain blockIdx -> problem-range map is already XCD-neutral.
+// Three launch shapes share the per-lane step of ip_core.h, all with 256-thread blocks (4 waves,
+// 2 waves per SIMD at ~190 VGPRs) and one problem per lane:
+//   k_newton_stream  k ungated steps; grid = the resident set (512 blocks), lanes walk the batch
+//                    with that stride and prefetch the next state into registers (HBM-streaming form)
+//   k_solve_tiled    the fused gated solve; one 512-problem tile per block, staged in LDS and
+//                    scheduled by expected step count (the benchmark's kernel)
+//   k_newton         one problem per lane in batch order: small batches, host-polled gated loops
+// Problems are independent and nothing is re-read, so there is no L2 locality to arrange: the
+// plain blockIdx -> problem-range map is XCD-neutral (blocks are dealt round-robin over the 8 XCDs).
 #include "ip_kernels.h"
 
 #include <cstdlib>
@@ -48,7 +53,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 }
 
 // ---------------------------------------------------------------------------------------
-// The hot kernel: up to k Newton steps per problem, state in registers between steps.
+// k_newton: up to k Newton steps per problem, state in registers between steps.
 //   GATED = false : exactly k steps (k presses of 'n', onedpath_ip.cpp:269-272)
 //   GATED = true  : before each step stop if gap < tol or the problem's step count reached
 //                   max_iter; problems already finished are skipped

@@ -27,6 +27,7 @@ struct rp_batch {
     double *d_aos;            // lazily allocated n * state_len doubles
     double *d_pos;            // lazily allocated 3 * n doubles (set_problems staging)
     double ungated_steps;     // per-problem count of ungated steps since the last init
+    unsigned long long *h_pinned;   // 8 pinned host words: counter / reduction read-backs without pageable staging
     hipEvent_t events[8];
     bool event_live[8];
 };
@@ -160,6 +161,7 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.order, n * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.counters, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_scratch, (4096 + 4) * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_pinned, 8 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemsetAsync(b->view.base, 0, fields * b->view.stride * elem_size(dtype), b->stream);
     if (e == hipSuccess) e = rp::launch_clear_progress(b->view, b->stream);
     if (e == hipSuccess) e = rp::launch_order(b->view, b->stream);
@@ -184,6 +186,7 @@ int rp_batch_destroy(rp_batch *b)
     if (b->view.order) (void)hipFree(b->view.order);
     if (b->view.counters) (void)hipFree(b->view.counters);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
+    if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     if (b->d_aos) (void)hipFree(b->d_aos);
     if (b->d_pos) (void)hipFree(b->d_pos);
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -345,11 +348,10 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
     // bounded host loop: every launch either finishes a problem or advances it by >= 1 step
     const int max_launches = max_iter / steps_per_launch + 2;
     for (int l = 0; l < max_launches; ++l) {
-        unsigned long long open = 0;
         RP_HIP(rp::launch_solve(b->view, b->params, steps_per_launch, gap_tol, max_iter, b->stream));
-        RP_HIP(hipMemcpyAsync(&open, b->view.counters, sizeof open, hipMemcpyDeviceToHost, b->stream));
+        RP_HIP(hipMemcpyAsync(b->h_pinned, b->view.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
         RP_HIP(hipStreamSynchronize(b->stream));
-        if (open == 0) break;
+        if (b->h_pinned[0] == 0) break;
     }
     return RP_OK;
 }
@@ -387,10 +389,10 @@ int rp_batch_reduce(rp_batch *b, rp_reduction *out)
 {
     RP_NEED(b);
     if (!out) return fail(RP_ERR_INVALID, "null output");
-    double h[4];
     int st = rp_batch_reduce_device(b, b->d_scratch + 4096);
     if (st != RP_OK) return st;
-    RP_HIP(hipMemcpyAsync(h, b->d_scratch + 4096, sizeof h, hipMemcpyDeviceToHost, b->stream));
+    double *h = reinterpret_cast<double *>(b->h_pinned + 4);
+    RP_HIP(hipMemcpyAsync(h, b->d_scratch + 4096, 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     RP_HIP(hipStreamSynchronize(b->stream));
     out->max_residual_sq = h[0];
     out->max_gap = h[1];

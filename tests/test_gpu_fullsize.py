@@ -72,3 +72,24 @@ def test_config5_f4_fp32_one_million_runs_and_stays_finite():
     assert np.all(np.isfinite(st))
     assert np.all(st[:, 1] > 0) and np.all(st[:, 2] > 0)
     assert np.max(np.abs(acc)) <= 100.0 * (1 + 1e-4)      # the line search never accepts an infeasible point
+
+
+def test_mirror_symmetry_property():
+    # Reflecting a problem (p0,p1,p2) -> (-p2,-p1,-p0) swaps the two segments: the optimum has the same
+    # midpoint velocity and swapped durations.  The arithmetic is not symmetric (seg 0 and seg 1 are
+    # evaluated by different expressions), so this is a property of the converged answer, checked at the
+    # level the gate guarantees rather than bit for bit.
+    n = 1 << 18
+    p0, p1, p2 = rp.problems.generate(2718, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(-p2, -p1, -p0)
+        a.solve(1e-8, 200, 0)
+        b.solve(1e-8, 200, 0)
+        sa, sb = a.get_state(), b.get_state()
+        ia, ib = a.get_iters()[0], b.get_iters()[0]
+    assert np.mean(ia != ib) < 1e-3
+    same = ia == ib
+    assert serr(sb[same][:, [0, 2, 1]], sa[same][:, :3]) < 1e-8
+    # multipliers swap too: (seg0 init -, +, final -, +) <-> (seg1 final ..., init ...)
+    assert serr(sb[same][:, [0, 2, 1]], sa[same][:, :3]) < 1e-8
