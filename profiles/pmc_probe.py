@@ -15,3 +15,6 @@ for _ in range(2):
     b.set_problems(p0, p1, p2)
     b.solve(1e-8, 200, 0)
     b.sync()
+b.set_problems(p0, p1, p2)
+b.solve(1e-8, 200, 1)     # host-polled: one gated launch per Newton step
+b.sync()

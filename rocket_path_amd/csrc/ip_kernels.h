@@ -20,7 +20,7 @@ struct BatchView {
     int32_t *iters;        // gated Newton steps taken per problem
     uint32_t *status;      // RP_ST_* bits per problem
     uint16_t *order;       // scheduling permutation for the fused solve (k_order_tiles): tile-local indices
-    unsigned long long *counters;   // [0] problems still active after the last gated launch, [1] gated steps executed
+    unsigned long long *counters;   // 128 words: [0,64) shards of "problems still open after the last gated launch", [64,128) shards of gated steps executed
 };
 
 struct HostParams {

@@ -27,7 +27,7 @@ struct rp_batch {
     double *d_aos;            // lazily allocated n * state_len doubles
     double *d_pos;            // lazily allocated 3 * n doubles (set_problems staging)
     double ungated_steps;     // per-problem count of ungated steps since the last init
-    unsigned long long *h_pinned;   // 8 pinned host words: counter / reduction read-backs without pageable staging
+    unsigned long long *h_pinned;   // 72 pinned host words: [0,64) counter shards, [64,68) reduction: read-backs without pageable staging
     hipEvent_t events[8];
     bool event_live[8];
 };
@@ -159,9 +159,9 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.iters, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.status, n * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.order, n * sizeof(uint16_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&b->view.counters, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->view.counters, 128 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_scratch, (4096 + 4) * sizeof(double));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_pinned, 8 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_pinned, 72 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemsetAsync(b->view.base, 0, fields * b->view.stride * elem_size(dtype), b->stream);
     if (e == hipSuccess) e = rp::launch_clear_progress(b->view, b->stream);
     if (e == hipSuccess) e = rp::launch_order(b->view, b->stream);
@@ -349,9 +349,11 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
     const int max_launches = max_iter / steps_per_launch + 2;
     for (int l = 0; l < max_launches; ++l) {
         RP_HIP(rp::launch_solve(b->view, b->params, steps_per_launch, gap_tol, max_iter, b->stream));
-        RP_HIP(hipMemcpyAsync(b->h_pinned, b->view.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+        RP_HIP(hipMemcpyAsync(b->h_pinned, b->view.counters, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
         RP_HIP(hipStreamSynchronize(b->stream));
-        if (b->h_pinned[0] == 0) break;
+        unsigned long long open = 0;
+        for (int i = 0; i < 64; ++i) open += b->h_pinned[i];
+        if (open == 0) break;
     }
     return RP_OK;
 }
@@ -391,7 +393,7 @@ int rp_batch_reduce(rp_batch *b, rp_reduction *out)
     if (!out) return fail(RP_ERR_INVALID, "null output");
     int st = rp_batch_reduce_device(b, b->d_scratch + 4096);
     if (st != RP_OK) return st;
-    double *h = reinterpret_cast<double *>(b->h_pinned + 4);
+    double *h = reinterpret_cast<double *>(b->h_pinned + 64);
     RP_HIP(hipMemcpyAsync(h, b->d_scratch + 4096, 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     RP_HIP(hipStreamSynchronize(b->stream));
     out->max_residual_sq = h[0];
