@@ -189,7 +189,7 @@ def main():
         except Exception:
             traffic = None
     line = {
-        "metric": "interior-point Newton steps/sec (whole node)",
+        "metric": "interior-point Newton steps/sec (whole node) + achieved HBM GB/s, 1M-problem batch",
         "value": steps_all / elapsed,
         "unit": "Newton steps/s",
         "n_gpus": world,

@@ -51,7 +51,8 @@ for k in fetch:
 if "k_solve_tiled<double, 3>" in out:
     out["k_solve_tiled_f3_f64"] = dict(out["k_solve_tiled<double, 3>"],
                                        expected="(16x8 + 4 + 4 + 2) B read + (11x8 + 4 + 4) B written per problem = 144.7 + 100.7 MB at n = 1,048,576")
-json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)       # read by bench.py
+json.dump(out, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag), "w"), indent=1)
 
 sq = {}
 for d in sq_dirs:
