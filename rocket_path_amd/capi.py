@@ -80,6 +80,10 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    if path is None and not os.path.exists(p) and os.path.exists("/opt/rocm/bin/hipcc"):
+        # a checkout without built artefacts (they are git-ignored): compile, never substitute
+        import subprocess
+        subprocess.call(["make", "-C", os.path.join(_HERE, "csrc"), "all"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if not os.path.exists(p):
         raise RuntimeError(
             "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
