@@ -128,11 +128,22 @@ def main():
     d_pos = torch.from_numpy(np.stack([p0, p1, p2])).to(torch.device("cuda", local_rank))
     lead = rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank)
     stream = lead.stream()
-    batches = [lead] + [rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) for _ in range(K + W - 1)]
+    # one batch per pass up to POOL of them (136 MB each at 1 Mi problems); longer runs cycle through the pool and
+    # pay the re-initialisation of a recycled batch inside the timed region (conservative: ~6 % of a pass)
+    POOL = 48
+    n_batches = max(1, min(K + W, POOL))
+    batches = [lead] + [rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) for _ in range(n_batches - 1)]
     ptrs = [d_pos[j].data_ptr() for j in range(3)]
     for b in batches:
         b.set_problems_device(*ptrs)
     lead.sync()
+
+    def pass_(index):
+        b = batches[index % n_batches]
+        if index >= n_batches:
+            b.set_problems_device(*ptrs)
+        b.solve(GAP_TOL, MAX_ITER, 0)
+        return b
     summary = torch.zeros(4, dtype=torch.float64, device=torch.device("cuda", local_rank))
 
     def barrier():
@@ -141,8 +152,8 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warmup: W untimed passes ----
-    for b in batches[:W]:
-        b.solve(GAP_TOL, MAX_ITER, 0)
+    for i in range(W):
+        pass_(i)
     if world > 1:
         sharding.allreduce_summary(summary.clone().to(coll_dev))     # RCCL communicator setup outside the timed region
     barrier()
@@ -150,18 +161,21 @@ def main():
     # ---- timed: exactly K passes, then the final summary reduction (+ all-reduce) ----
     t0 = time.perf_counter()
     lead.event_record(0)
-    for b in batches[W:]:
-        b.solve(GAP_TOL, MAX_ITER, 0)
+    last = lead
+    for i in range(W, W + K):
+        last = pass_(i)
     lead.event_record(1)
-    batches[-1].reduce_device(summary.data_ptr())
+    last.reduce_device(summary.data_ptr())
     lead.sync()
     summary = sharding.allreduce_summary(summary.to(coll_dev))
     barrier()
     elapsed = time.perf_counter() - t0
 
     kernel_ms = lead.event_elapsed_ms(0, 1) / max(K, 1)
-    steps_local = sum(b.reduce()["total_steps"] for b in batches[W:])
-    conv_local = sum(b.reduce()["n_converged"] for b in batches[W:])
+    # every pass solves the same seeded batch from the same start: steps per pass are those of any solved batch
+    one = last.reduce()
+    steps_local = one["total_steps"] * K
+    conv_local = one["n_converged"] * K
     t = torch.tensor([elapsed, steps_local, conv_local], dtype=torch.float64, device=coll_dev)
     if world > 1:
         tm = t[:1].clone()
@@ -226,13 +240,25 @@ def main():
         },
     }
 
+    # The fused solve is fp64-ALU bound, so next to the (algorithmic) HBM roofline the same launch is priced against
+    # the fp64 vector peak: flop per Newton step from the rocprofv3 SQ counters of profiles/r1_sq_counters.json
+    # (240 FMA x 2 + 100 MUL + 44 ADD + 19 RCP per lane-step of the 12-step fused kernel).
+    FLOP_PER_STEP, FP64_PEAK_TFLOPS = 643.0, 78.6
+    tflops = FLOP_PER_STEP * steps_per_launch / (kernel_ms * 1e-3) / 1e12
+    line["compute_roofline"] = {"bound": "fp64 vector ALU", "flop_per_newton_step": FLOP_PER_STEP, "achieved": tflops,
+                                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
+                                "note": "493 VALU instructions per step, 403 of them fp64; measured issue cost 2.1 ns per fp64 "
+                                        "wave-instruction per SIMD (profiles/probes/valu_probe.hip) => 1.03 us of pure issue per "
+                                        "wave-step against 1.4 us achieved; idle lane-steps of the gated solve (~10 %) are not "
+                                        "counted as flops"}
+
     if not args.no_extras:
         # (a) one launch per Newton step: the HBM-streaming form of the same step (216 B really move per step).
         #     cold = every launch on a batch not touched since its init (state comes from HBM);
         #     warm = the same 128 MiB batch stepped again and again (state stays in the 256 MiB Infinity Cache);
         #     probe = the same kernel with zero steps: its 16 loads + 11 stores per problem and nothing else,
         #             i.e. what this access pattern can reach on this box (the kernel's own ceiling).
-        spare = batches[W:]
+        spare = batches[:min(len(batches), 20)]
 
         def reinit():
             for b in spare:
