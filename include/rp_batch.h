@@ -57,6 +57,7 @@ typedef enum {
 #define RP_ST_MAXITER 2u    /* step cap reached before the gate */
 #define RP_ST_NONFINITE 4u  /* a variable became NaN/inf */
 #define RP_ST_INFEASIBLE 8u /* some c_i > 0 at the last gate check (constraintsSatisfied false) */
+#define RP_ST_STALLED 16u   /* stall detector fired (only when rp_params.stall_window > 0); the problem is left alone from then on */
 
 /* Solver constants, defaults = the reference's compile-time values. */
 typedef struct {
@@ -66,7 +67,9 @@ typedef struct {
     double backtrack;         /* 0.5     onedpath_ip.cpp:927, 944 */
     double armijo;            /* 0.01    onedpath_ip.cpp:941 */
     int32_t max_backtracks;   /* 100     onedpath_ip.cpp:919, 934 */
-    int32_t reserved;
+    int32_t stall_window;     /* 0 = off (the reference's behaviour: it keeps stepping, e.g. from initStuck, onedpath_ip.cpp:177-199).
+                                 w > 0: in a gated solve, a problem whose surrogate gap has not halved for w consecutive steps of
+                                 one launch is marked RP_ST_STALLED and stops -- SURVEY.md 8f row 4; never changes a converging run */
 } rp_params;
 
 /* Batch-wide reduction, the payload of the one cross-GPU collective (max / max / sum / sum). */

@@ -14,7 +14,7 @@ RP_OK = 0
 RP_ERR_INVALID, RP_ERR_DEVICE, RP_ERR_NOMEM, RP_ERR_UNSUPPORTED, RP_ERR_NO_DEVICE = 1, 2, 3, 4, 5
 VARIANT_F3, VARIANT_F4 = 3, 4
 DTYPE_F64, DTYPE_F32 = 0, 1
-ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_INFEASIBLE = 1, 2, 4, 8
+ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_INFEASIBLE, ST_STALLED = 1, 2, 4, 8, 16
 
 
 class RpError(RuntimeError):
@@ -26,7 +26,7 @@ class RpError(RuntimeError):
 class Params(ctypes.Structure):
     _fields_ = [("accel_limit", ctypes.c_double), ("mu_divisor", ctypes.c_double),
                 ("boundary_fraction", ctypes.c_double), ("backtrack", ctypes.c_double),
-                ("armijo", ctypes.c_double), ("max_backtracks", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("armijo", ctypes.c_double), ("max_backtracks", ctypes.c_int32), ("stall_window", ctypes.c_int32)]
 
 
 class Reduction(ctypes.Structure):

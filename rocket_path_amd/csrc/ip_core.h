@@ -107,6 +107,7 @@ template <typename T> struct KParams {
     T armijo;       // 0.01
     T c_floor;      // L * eps / 256: the shift applied to every c_i before it is inverted (see c_guard)
     int max_bt;     // 100
+    int stall_window;   // 0 = off; see rp_params.stall_window
 };
 
 // The per-problem constants the step needs (enum V 11..15 reduced to velocities and deltas).

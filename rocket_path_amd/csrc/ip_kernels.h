@@ -26,6 +26,7 @@ struct BatchView {
 struct HostParams {
     double accel_limit, mu_divisor, boundary_fraction, backtrack, armijo;
     int max_backtracks;
+    int stall_window;
 };
 
 inline int state_len(int variant) { return variant == 4 ? 12 : 16; }

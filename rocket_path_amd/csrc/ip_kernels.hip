@@ -53,6 +53,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
     kp.armijo = (T)hp.armijo;
     kp.c_floor = (T)hp.accel_limit * (sizeof(T) == 8 ? (T)8.673617379884035e-19 : (T)4.656612873077393e-10);   // L * eps / 256
     kp.max_bt = hp.max_backtracks;
+    kp.stall_window = hp.stall_window;
     return kp;
 }
 
@@ -77,11 +78,17 @@ __device__ __forceinline__ void run_lane(const Prob<T> &pr, const KParams<T> &kp
     accel_grads(pr, v, e);
 
     bool done = false;
+    T best_gap = T(3.0e38);      // stall detector state (off unless kp.stall_window > 0)
+    int since_best = 0;
     for (int s = 0; s < k; ++s) {
         const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
         if (GATED) {
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
             if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; break; }
+            if (kp.stall_window > 0) {
+                if (gap < T(0.5) * best_gap) { best_gap = gap; since_best = 0; }
+                else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
+            }
         }
         newton_step<T, VARIANT>(pr, kp, gap, v, t0, t1, lam, e);
         ++it;
@@ -116,7 +123,7 @@ k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
     if (GATED && valid) {
         it = iters[i];
         st = status[i];
-        active = (st & (RP_ST_CONVERGED | RP_ST_MAXITER)) == 0;
+        active = (st & (RP_ST_CONVERGED | RP_ST_MAXITER | RP_ST_STALLED)) == 0;
     }
     int steps_here = 0;
     bool still_open = false;
@@ -314,7 +321,7 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T to
 #pragma unroll 1
     for (int round = 0; round < 2; ++round) {
         const int j = mine[round];
-        if (j >= 0 && (s_st[j] & (RP_ST_CONVERGED | RP_ST_MAXITER)) == 0) {
+        if (j >= 0 && (s_st[j] & (RP_ST_CONVERGED | RP_ST_MAXITER | RP_ST_STALLED)) == 0) {
             T v = sm[0][j], t0 = sm[1][j], t1 = sm[2][j];
             T lam[NC];
 #pragma unroll

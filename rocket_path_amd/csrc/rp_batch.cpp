@@ -68,6 +68,7 @@ void default_params(rp::HostParams &hp)
     hp.backtrack = 0.5;
     hp.armijo = 0.01;
     hp.max_backtracks = 100;
+    hp.stall_window = 0;
 }
 
 int reset_progress(rp_batch *b)
@@ -125,7 +126,7 @@ void rp_params_default(rp_params *p)
     p->backtrack = hp.backtrack;
     p->armijo = hp.armijo;
     p->max_backtracks = hp.max_backtracks;
-    p->reserved = 0;
+    p->stall_window = hp.stall_window;
 }
 
 int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device, void *stream)
@@ -199,7 +200,7 @@ int rp_batch_set_params(rp_batch *b, const rp_params *p)
     if (!b || !p) return fail(RP_ERR_INVALID, "null argument");
     if (!(p->accel_limit > 0) || !(p->mu_divisor > 0) || !(p->boundary_fraction > 0 && p->boundary_fraction <= 1) ||
         !(p->backtrack > 0 && p->backtrack < 1) || !(p->armijo >= 0 && p->armijo < 1) || p->max_backtracks < 0 ||
-        p->max_backtracks > 4096)      // every device loop must stay short: a runaway kernel takes the GPU with it
+        p->max_backtracks > 4096 || p->stall_window < 0)      // every device loop must stay short: a runaway kernel takes the GPU with it
         return fail(RP_ERR_INVALID, "parameter out of range");
     b->params.accel_limit = p->accel_limit;
     b->params.mu_divisor = p->mu_divisor;
@@ -207,6 +208,7 @@ int rp_batch_set_params(rp_batch *b, const rp_params *p)
     b->params.backtrack = p->backtrack;
     b->params.armijo = p->armijo;
     b->params.max_backtracks = p->max_backtracks;
+    b->params.stall_window = p->stall_window;
     return RP_OK;
 }
 
@@ -219,7 +221,7 @@ int rp_batch_get_params(const rp_batch *b, rp_params *p)
     p->backtrack = b->params.backtrack;
     p->armijo = b->params.armijo;
     p->max_backtracks = b->params.max_backtracks;
-    p->reserved = 0;
+    p->stall_window = b->params.stall_window;
     return RP_OK;
 }
 

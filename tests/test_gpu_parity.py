@@ -393,3 +393,28 @@ def test_tiled_solve_f4_fp32_matches_plain_kernel():
         b.solve(1e-3, 25, 5)
         assert np.array_equal(a.get_state(), b.get_state())
         assert np.array_equal(a.get_iters()[0], b.get_iters()[0])
+
+
+# ---------------------------------------------------------------- stall detector, off by default
+def test_stall_detector_is_off_by_default_and_stops_the_stuck_state(g3):
+    n = 1024
+    with rp.Batch(n) as b:
+        assert b.get_params().stall_window == 0
+        b.init_stuck()                        # initStuck, onedpath_ip.cpp:177-199: the gap stays ~2.08 for ever
+        b.solve(1e-8, 60, 0)
+        it, st = b.get_iters()
+        assert np.all(it == 60) and np.all(st & rp.ST_MAXITER) and not np.any(st & rp.ST_STALLED)
+        b.set_params(stall_window=8)
+        b.init_stuck()
+        b.solve(1e-8, 200, 0)
+        it, st = b.get_iters()
+        assert np.all(st & rp.ST_STALLED) and np.all(it < 40) and not np.any(st & rp.ST_CONVERGED)
+        stuck = b.get_state()
+        b.solve(1e-8, 200, 0)                 # a stalled problem is left alone
+        assert np.array_equal(b.get_state(), stuck)
+        # a converging batch is untouched by the detector: bit-identical to the golden run without it
+        b.set_state(g3["init"][:n])
+        b.solve(1e-8, 200, 0)
+        it, st = b.get_iters()
+        assert np.array_equal(it, g3["iters"][:n]) and np.all(st == rp.ST_CONVERGED)
+        assert serr(b.get_state()[:, :3], g3["gated"][:n, :3]) < TOL
