@@ -66,9 +66,14 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 #ifndef RP_NEWTON_WAVES
 #define RP_NEWTON_WAVES 2     // minimum waves per SIMD the register allocator must leave room for
 #endif
+#ifndef RP_TILED_WAVES
+#define RP_TILED_WAVES 2
+#endif
 
 // The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
-template <typename T, int VARIANT, bool GATED>
+// STALL: compile the stall detector in (two more live registers); the tiled solve instantiates both
+// forms and picks by rp_params.stall_window, so the default (off) pays nothing for it.
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED>
 __device__ __forceinline__ void run_lane(const Prob<T> &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open)
@@ -85,7 +90,7 @@ __device__ __forceinline__ void run_lane(const Prob<T> &pr, const KParams<T> &kp
         if (GATED) {
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
             if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; break; }
-            if (kp.stall_window > 0) {
+            if (STALL && kp.stall_window > 0) {
                 if (gap < T(0.5) * best_gap) { best_gap = gap; since_best = 0; }
                 else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
             }
@@ -284,16 +289,15 @@ k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__r
     }
 }
 
-template <typename T, int VARIANT>
-__global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
+template <typename T, int VARIANT, bool STALL>
+__global__ void __launch_bounds__(kBlock, RP_TILED_WAVES)
 k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T tol, int max_iter,
               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
               const uint16_t *__restrict__ order)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
-    constexpr int NF = CB + 5;
-    __shared__ T sm[NF][kTile];
+    __shared__ T sm[CB][kTile];            // the mutable fields only; the five constants are read once per problem
     __shared__ int32_t s_it[kTile];
     __shared__ uint32_t s_st[kTile];
 
@@ -303,7 +307,7 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T to
 
     // -- stage the tile: field-major in LDS, every global access a full coalesced segment
 #pragma unroll
-    for (int f = 0; f < NF; ++f)
+    for (int f = 0; f < CB; ++f)
         for (int j = tid; j < count; j += kBlock) sm[f][j] = base[(size_t)f * stride + first + j];
     for (int j = tid; j < count; j += kBlock) { s_it[j] = iters[first + j]; s_st[j] = status[first + j]; }
     // this thread's two scheduled problems: sorted chunks `wave` and `7 - wave`
@@ -326,15 +330,19 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T to
             T lam[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) lam[c] = sm[3 + c][j];
-            Prob<T> pr;
-            pr.v0 = sm[CB + 1][j];
-            pr.v2 = sm[CB + 4][j];
-            pr.dx0 = sm[CB + 2][j] - sm[CB + 0][j];
-            pr.dx1 = sm[CB + 3][j] - sm[CB + 2][j];
+            Prob<T> pr;     // constants: a gather inside the tile's 4 KiB window of each field, once per problem
+            {
+                const T *g = base + first + j;
+                const T q0 = g[(size_t)(CB + 0) * stride], q1 = g[(size_t)(CB + 2) * stride], q2 = g[(size_t)(CB + 3) * stride];
+                pr.v0 = g[(size_t)(CB + 1) * stride];
+                pr.v2 = g[(size_t)(CB + 4) * stride];
+                pr.dx0 = q1 - q0;
+                pr.dx1 = q2 - q1;
+            }
             int it = s_it[j];
             uint32_t st = s_st[j];
             bool still_open = false;
-            run_lane<T, VARIANT, true>(pr, kp, max_iter > 0 ? max_iter : 1, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+            run_lane<T, VARIANT, true, STALL>(pr, kp, max_iter > 0 ? max_iter : 1, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
             open_any = open_any || still_open;
             sm[0][j] = v;
             sm[1][j] = t0;
@@ -627,8 +635,13 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
 {
     if (k < 0 || b.n == 0) return hipSuccess;     // k == 0: load/store only (bandwidth probe, see rp_batch_step)
     // resident set: 256 CUs x 2 blocks (2 waves per SIMD); larger batches are walked with that stride
+    // k <= 2 is memory-bound: grid = the resident set (256 CUs x 2 blocks) so that each lane walks 8 problems at
+    // 1 Mi and its register prefetch hides the HBM latency.  Larger k is arithmetic-bound and prefers more, shorter
+    // blocks (measured at k = 12: 512 -> 47.1, 1024 -> 48.2, 2048 -> 49.5 G steps/s; at k = 1 2048 costs 25 %).
+    static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override
+    const unsigned cap = grid_env ? (unsigned)atoi(grid_env) : (k <= 2 ? 512u : 2048u);
     unsigned grid = grid_for(b.n);
-    if (grid > 512u) grid = 512u;
+    if (grid > cap) grid = cap;
     RP_DISPATCH(b, hipLaunchKernelGGL((k_newton_stream<T, V>), dim3(grid), dim3(kBlock), 0, stream,
                                        (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
     return hipGetLastError();
@@ -648,9 +661,14 @@ hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double g
         return hipGetLastError();
     }
     const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_tiled<T, V>), dim3(grid), dim3(kBlock), 0, stream,
-                                       (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
-                                       b.iters, b.status, b.counters, (const uint16_t *)b.order));
+    if (hp.stall_window > 0)
+        RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_tiled<T, V, true>), dim3(grid), dim3(kBlock), 0, stream,
+                                           (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
+                                           b.iters, b.status, b.counters, (const uint16_t *)b.order));
+    else
+        RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_tiled<T, V, false>), dim3(grid), dim3(kBlock), 0, stream,
+                                           (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
+                                           b.iters, b.status, b.counters, (const uint16_t *)b.order));
     return hipGetLastError();
 }
 
