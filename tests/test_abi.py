@@ -89,3 +89,23 @@ def test_headless_shell_without_gpu_fails_cleanly():
         pytest.skip("GPU present")
     r = subprocess.run([exe, "--keys", "n s"], capture_output=True, text=True)
     assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/problem.h"), reason="reference tree not present (GPU box)")
+def test_plugin_compiles_against_the_reference_problem_header(tmp_path):
+    """The drop-in claim of INTEGRATION.md: BatchedOneDPathIP derives from the reference's own
+    `struct Problem` (problem.h:3-14) when built inside the reference tree, and can stand in
+    rocket_path.cpp's table of `Problem *` (rocket_path.cpp:38-44)."""
+    src = tmp_path / "dropin.cpp"
+    src.write_text(
+        '#include "batched_problem.h"\n'
+        'static BatchedOneDPathIP g_problem3(4, RP_VARIANT_F3, RP_DTYPE_F64);\n'
+        'static BatchedOneDPathIP g_problem4(4, RP_VARIANT_F4, RP_DTYPE_F32);\n'
+        'static Problem * g_problems[] = { &g_problem3, &g_problem4 };\n'
+        'int main() { for (Problem * p : g_problems) p->init(); g_problems[0]->onKey(\'n\'); return 0; }\n')
+    host = os.path.join(ROOT, "rocket_path_amd", "csrc", "host")
+    r = subprocess.run(["g++", "-std=c++14", "-Wall", "-Werror", "-fsyntax-only", "-DRP_USE_REFERENCE_PROBLEM_H",
+                        "-I", "/root/reference", "-I", host,
+                        "-I", os.path.join(ROOT, "include"), str(src), os.path.join(host, "batched_problem.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
