@@ -93,3 +93,37 @@ def test_mirror_symmetry_property():
     assert serr(sb[same][:, [0, 2, 1]], sa[same][:, :3]) < 1e-8
     # multipliers swap too: (seg0 init -, +, final -, +) <-> (seg1 final ..., init ...)
     assert serr(sb[same][:, [0, 2, 1]], sa[same][:, :3]) < 1e-8
+
+
+def test_non_monotone_stress_one_million(oracle):
+    # mid position outside [start, end] for most problems: the optimum has vel1 ~ 0 and the scale-aware tolerance matters
+    n = 1 << 20
+    p0, p1, p2 = rp.problems.generate(4321, 0, n, rp.problems.DIST_NON_MONOTONE)
+    with rp.Batch(n) as b:
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 200, 0)
+        it, status = b.get_iters()
+        st = b.get_state()
+    assert np.all(np.isfinite(st)) and np.all(status == rp.ST_CONVERGED) and it.max() < 200
+    sl = slice(500000, 500000 + 16384)
+    aos = oracle.batch_init_feasible(3, p0[sl], p1[sl], p2[sl])
+    it_o, _ = oracle.batch_solve_gated(3, aos, 1e-8, 200)
+    assert np.array_equal(it[sl], it_o) and serr(st[sl, :3], aos[:, :3]) < 1e-10
+
+
+def test_five_million_problems_ragged(oracle):
+    # 64-bit indexing and a ragged last tile far from the start of the arrays (field offsets beyond 2^31 bytes... at f64
+    # 16 fields x 5,000,003 x 8 B = 640 MB; per-field stride 40 MB)
+    n = 5_000_003
+    p0, p1, p2 = rp.problems.generate(777, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as b:
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 200, 0)
+        it, status = b.get_iters()
+        r = b.reduce()
+        st = b.get_state()
+    assert np.all(status == rp.ST_CONVERGED) and r["n_converged"] == n and r["total_steps"] == float(it.sum())
+    for sl in (slice(0, 8192), slice(n - 8192, n)):
+        aos = oracle.batch_init_feasible(3, p0[sl], p1[sl], p2[sl])
+        it_o, _ = oracle.batch_solve_gated(3, aos, 1e-8, 200)
+        assert np.array_equal(it[sl], it_o) and serr(st[sl, :3], aos[:, :3]) < 1e-10
