@@ -232,7 +232,7 @@ static double packet_tree(const double *sq, int start, int len, int lane)
 
 static double eigen_squared_norm(const double *v, int n)
 {
-    double sq[MAXN + 1];
+    double sq[16 + 1];      /* n <= 16: orc_colpiv_qr_solve accepts systems up to 16 x 16 */
     const int npk = n / 2;
     int i;
     double res;
