@@ -73,9 +73,27 @@ def cpu_baseline(sample_n):
     t0 = time.perf_counter()
     _, total1 = orc.batch_solve_gated(3, aos1, GAP_TOL, MAX_ITER, threads=1)
     dt1 = time.perf_counter() - t0
-    return {"value": total / dt, "unit": "Newton steps/s", "cores": threads, "kind": "port",
-            "sample": "first %d problems of the same batch, same gate, %d steps in %.2f s on %d threads" % (sample_n, total, dt, threads),
-            "single_core_value": total1 / dt1}
+    out = {"value": total / dt, "unit": "Newton steps/s", "cores": threads, "kind": "port",
+           "sample": "first %d problems of the same batch, same gate, %d steps in %.2f s on %d threads" % (sample_n, total, dt, threads),
+           "single_core_value": total1 / dt1}
+    # the same restatement with its 11x11 solve done by the reference's own vendored Eigen 3.3.0 QR (oracle/_ref,
+    # prebuilt where /root/reference exists): 78 % of a reference step is that call
+    try:
+        from oracle_api import have_ref
+        if have_ref():
+            orc_e = Oracle(eigen=True)
+            aos2 = orc_e.batch_init_feasible(3, p0, p1, p2)
+            t0 = time.perf_counter()
+            _, total2 = orc_e.batch_solve_gated(3, aos2, GAP_TOL, MAX_ITER, threads=threads)
+            dt2 = time.perf_counter() - t0
+            aos3 = orc_e.batch_init_feasible(3, p0[:n1], p1[:n1], p2[:n1])
+            t0 = time.perf_counter()
+            _, total3 = orc_e.batch_solve_gated(3, aos3, GAP_TOL, MAX_ITER, threads=1)
+            dt3 = time.perf_counter() - t0
+            out["with_reference_eigen_qr"] = {"value": total2 / dt2, "single_core_value": total3 / dt3, "cores": threads}
+    except Exception as exc:      # the baseline must never take the benchmark down
+        out["with_reference_eigen_qr"] = {"error": str(exc)}
+    return out
 
 
 def main():

@@ -574,14 +574,20 @@ void orc_init_feasible(int variant, double pos0, double pos1, double pos2, doubl
     var[base + 4] = 0;
 }
 
-int orc_solve_gated(int variant, double *var, double gap_tol, int max_iter)
+int orc_solve_gated_ex(int variant, double *var, double gap_tol, int max_iter, orc_qr_solver solver)
 {
+    double d[MAXN];
     int it;
     for (it = 0; it < max_iter; ++it) {
         if (orc_gap(variant, var) < gap_tol) break;
-        orc_step(variant, var, NULL);
+        orc_step_ex(variant, var, d, NULL, solver);
     }
     return it;
+}
+
+int orc_solve_gated(int variant, double *var, double gap_tol, int max_iter)
+{
+    return orc_solve_gated_ex(variant, var, gap_tol, max_iter, NULL);
 }
 
 /* ------------------------------------------------------------------ */
@@ -625,6 +631,12 @@ void orc_batch_steps(int variant, size_t n, double *aos, int k, int threads)
 int64_t orc_batch_solve_gated(int variant, size_t n, double *aos, double gap_tol, int max_iter,
                               int32_t *iters, int threads)
 {
+    return orc_batch_solve_gated_ex(variant, n, aos, gap_tol, max_iter, iters, threads, NULL);
+}
+
+int64_t orc_batch_solve_gated_ex(int variant, size_t n, double *aos, double gap_tol, int max_iter,
+                                 int32_t *iters, int threads, orc_qr_solver solver)
+{
     const size_t M = (size_t)orc_state_len(variant);
     const int nt = pick_threads(threads);
     int64_t total = 0;
@@ -632,7 +644,7 @@ int64_t orc_batch_solve_gated(int variant, size_t n, double *aos, double gap_tol
     (void)nt;
 #pragma omp parallel for num_threads(nt) schedule(static) reduction(+ : total)
     for (i = 0; i < (long long)n; ++i) {
-        const int it = orc_solve_gated(variant, aos + (size_t)i * M, gap_tol, max_iter);
+        const int it = orc_solve_gated_ex(variant, aos + (size_t)i * M, gap_tol, max_iter, solver);
         if (iters) iters[i] = it;
         total += it;
     }

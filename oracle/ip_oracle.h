@@ -115,6 +115,10 @@ void   orc_batch_steps(int variant, size_t n, double *aos, int k, int threads);
 /* iters[i] receives the gated step count of problem i; returns the sum over the batch */
 int64_t orc_batch_solve_gated(int variant, size_t n, double *aos, double gap_tol, int max_iter,
                               int32_t *iters, int threads);
+/* the same with the linear solve delegated (oracle/_ref's Eigen QR is re-entrant: all state on the stack) */
+int    orc_solve_gated_ex(int variant, double *var, double gap_tol, int max_iter, orc_qr_solver solver);
+int64_t orc_batch_solve_gated_ex(int variant, size_t n, double *aos, double gap_tol, int max_iter,
+                                 int32_t *iters, int threads, orc_qr_solver solver);
 int    orc_hw_threads(void);
 
 /* ---- trajectory sampling (plot data), onedpath_ip.cpp:1015-1088 ---- */

@@ -61,6 +61,9 @@ class Oracle:
         L.orc_batch_solve_gated.restype = ctypes.c_int64
         L.orc_batch_solve_gated.argtypes = [ctypes.c_int, ctypes.c_size_t, _dp, ctypes.c_double, ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_int32), ctypes.c_int]
+        L.orc_batch_solve_gated_ex.restype = ctypes.c_int64
+        L.orc_batch_solve_gated_ex.argtypes = [ctypes.c_int, ctypes.c_size_t, _dp, ctypes.c_double, ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_void_p]
         L.orc_sample_trajectory.argtypes = [ctypes.c_int, _dp, _dp, _dp]
         L.orc_gen_problems.argtypes = [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, _dp, _dp, _dp]
         self.solver = None
@@ -185,13 +188,8 @@ class Oracle:
         assert aos.flags.c_contiguous and aos.dtype == np.float64
         n = aos.shape[0]
         iters = np.zeros(n, dtype=np.int32)
-        if self.solver is None:
-            total = self.lib.orc_batch_solve_gated(variant, n, _p(aos), tol, max_iter,
-                                                   iters.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), threads)
-        else:
-            for i, row in enumerate(aos):
-                iters[i] = self.solve_gated(variant, row, tol, max_iter)
-            total = int(iters.sum())
+        total = self.lib.orc_batch_solve_gated_ex(variant, n, _p(aos), tol, max_iter,
+                                                  iters.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), threads, self.solver)
         return iters, total
 
     def hw_threads(self):
