@@ -131,6 +131,11 @@ RP_API int rp_batch_reduce(rp_batch *b, rp_reduction *out);                   /*
 /* Writes the 4 doubles of rp_reduction to device memory the caller owns, asynchronously on
  * the batch stream: the buffer a multi-GPU caller hands to its RCCL all-reduce. */
 RP_API int rp_batch_reduce_device(rp_batch *b, double *d_out4);
+/* For single-process multi-GPU hosts (csrc/host/sharded_problem.cpp): the same reduction into the batch's OWN
+ * 4-double device slot, whose address is returned (asynchronous; all-reduce it in place on rp_batch_stream()),
+ * and the synchronous read-back of that slot afterwards. */
+RP_API int rp_batch_summary_device(rp_batch *b, double **d_out4);
+RP_API int rp_batch_summary_read(rp_batch *b, rp_reduction *out);
 /* Plot data (plotTrajectory/plotAcceleration, onedpath_ip.cpp:1015-1088): per problem 66
  * positions (33 per segment) and 4 end accelerations, host arrays, synchronous. */
 RP_API int rp_batch_sample(rp_batch *b, double *pos66, double *acc4);

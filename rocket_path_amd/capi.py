@@ -63,6 +63,8 @@ SIGNATURES = {
     "rp_batch_get_iters": (ctypes.c_int, [_vp, _vp, _vp]),
     "rp_batch_reduce": (ctypes.c_int, [_vp, ctypes.POINTER(Reduction)]),
     "rp_batch_reduce_device": (ctypes.c_int, [_vp, _vp]),
+    "rp_batch_summary_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "rp_batch_summary_read": (ctypes.c_int, [_vp, ctypes.POINTER(Reduction)]),
     "rp_batch_sample": (ctypes.c_int, [_vp, _vp, _vp]),
     "rp_batch_sync": (ctypes.c_int, [_vp]),
     "rp_batch_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),

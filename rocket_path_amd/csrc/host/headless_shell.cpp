@@ -5,7 +5,9 @@
 // to the current problem, F-keys switch problems.  The F3 and F4 slots hold the batched GPU
 // problems; F1/F2 (fixptpath, onedpath) are out of scope and left empty.
 //
-//   rp_headless [--n N] [--seed S] [--f4] [--f32] [--keys "i n n s"] [--solve]
+//   rp_headless [--n N] [--seed S] [--f4] [--f32] [--gpus G] [--keys "i n n s"] [--solve]
+//
+// --gpus G (G >= 1) puts a ShardedOneDPathIP (G devices, one process, RCCL summary) in the F3 slot.
 //
 // --keys takes space-separated tokens: single characters are onKey() (SPACE for ' '),
 // F3/F4 switch problems, HOME END PGUP PGDN LEFT RIGHT UP DOWN are special keys, nK repeats
@@ -18,6 +20,7 @@
 #include <vector>
 
 #include "batched_problem.h"
+#include "sharded_problem.h"
 
 namespace {
 
@@ -38,6 +41,7 @@ int main(int argc, char **argv)
     size_t n = 1;
     uint64_t seed = 0;
     bool haveSeed = false, solve = false, f32 = false, startF4 = false;
+    int gpus = 0;
     std::string keys = "s";
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--n") && i + 1 < argc) n = (size_t)strtoull(argv[++i], nullptr, 10);
@@ -46,9 +50,36 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--solve")) solve = true;
         else if (!strcmp(argv[i], "--f32")) f32 = true;
         else if (!strcmp(argv[i], "--f4")) startF4 = true;
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     if (n == 0) { fprintf(stderr, "--n must be positive\n"); return 2; }
+
+    if (gpus > 0) {     // the sharded F3 problem: keys and the summary only (no per-lane print)
+        ShardedOneDPathIP sharded(n, gpus, RP_VARIANT_F3, f32 ? RP_DTYPE_F32 : RP_DTYPE_F64);
+        if (!sharded.ok()) return 1;
+        sharded.init();
+        if (haveSeed) {
+            std::vector<double> p0(n), p1(n), p2(n);
+            for (size_t i = 0; i < n; ++i) {
+                p0[i] = 1000.0 * u01(seed, 3 * i + 1);
+                p1[i] = p0[i] + 10.0 + 500.0 * u01(seed, 3 * i + 2);
+                p2[i] = p1[i] + 10.0 + 500.0 * u01(seed, 3 * i + 3);
+            }
+            sharded.setProblems(p0.data(), p1.data(), p2.data());
+        }
+        sharded.onActivate();
+        if (solve) sharded.solve();
+        std::istringstream in(keys);
+        std::string tok;
+        while (in >> tok) {
+            if (tok == "SPACE") sharded.onKey(' ');
+            else if (tok.size() > 1 && tok[0] == 'n') sharded.step(atoi(tok.c_str() + 1));
+            else if (tok.size() == 1) sharded.onKey((unsigned char)tok[0]);
+            else { fprintf(stderr, "unknown key token %s\n", tok.c_str()); return 2; }
+        }
+        return 0;
+    }
 
     BatchedOneDPathIP problem3(n, RP_VARIANT_F3, f32 ? RP_DTYPE_F32 : RP_DTYPE_F64);
     BatchedOneDPathIP problem4(n, RP_VARIANT_F4, f32 ? RP_DTYPE_F32 : RP_DTYPE_F64);

@@ -405,6 +405,30 @@ int rp_batch_reduce(rp_batch *b, rp_reduction *out)
     return RP_OK;
 }
 
+int rp_batch_summary_device(rp_batch *b, double **d_out4)
+{
+    RP_NEED(b);
+    if (!d_out4) return fail(RP_ERR_INVALID, "null output");
+    int st = rp_batch_reduce_device(b, b->d_scratch + 4096);
+    if (st != RP_OK) return st;
+    *d_out4 = b->d_scratch + 4096;
+    return RP_OK;
+}
+
+int rp_batch_summary_read(rp_batch *b, rp_reduction *out)
+{
+    RP_NEED(b);
+    if (!out) return fail(RP_ERR_INVALID, "null output");
+    double *h = reinterpret_cast<double *>(b->h_pinned + 64);
+    RP_HIP(hipMemcpyAsync(h, b->d_scratch + 4096, 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    RP_HIP(hipStreamSynchronize(b->stream));
+    out->max_residual_sq = h[0];
+    out->max_gap = h[1];
+    out->n_converged = h[2];
+    out->total_steps = h[3];
+    return RP_OK;
+}
+
 int rp_batch_sample(rp_batch *b, double *pos66, double *acc4)
 {
     RP_NEED(b);

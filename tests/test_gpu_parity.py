@@ -418,3 +418,24 @@ def test_stall_detector_is_off_by_default_and_stops_the_stuck_state(g3):
         it, st = b.get_iters()
         assert np.array_equal(it, g3["iters"][:n]) and np.all(st == rp.ST_CONVERGED)
         assert serr(b.get_state()[:, :3], g3["gated"][:n, :3]) < TOL
+
+
+def test_sharded_cpp_host_with_rccl_on_one_device():
+    # the single-process multi-GPU host class (csrc/host/sharded_problem.cpp) on the one device this box has:
+    # shard bookkeeping, ncclCommInitAll, the grouped MAX/SUM all-reduce of the device-resident summary
+    exe = os.path.join(ROOT, "rocket_path_amd", "lib", "rp_headless")
+    n = 4096
+    out = subprocess.run([exe, "--gpus", "1", "--n", str(n), "--seed", "12345", "--solve", "--keys", "s"],
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("Batch:")][-1]
+    p0, p1, p2 = rp.problems.generate(12345, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as b:
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 200, 0)
+        r = b.reduce()
+    assert "converged: %d" % n in line and "steps: %.0f" % r["total_steps"] in line
+    assert ("max surrogate gap: %g" % r["max_gap"]) in line
+    # asking for more devices than exist is refused, not faked
+    bad = subprocess.run([exe, "--gpus", "64", "--n", "128", "--keys", "s"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "visible" in bad.stderr
