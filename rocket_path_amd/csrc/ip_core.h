@@ -111,10 +111,21 @@ template <typename T> struct KParams {
 };
 
 // The per-problem constants the step needs (enum V 11..15 reduced to velocities and deltas).
-template <typename T> struct Prob {
-    T v0, v2;      // vel0X, vel2X
+// ZV = "vel0X and vel2X are zero for every problem of the batch".  Every start state the reference has
+// leaves them at zero (initDefault / initStuck, onedpath_ip.cpp:179-186, 203-210) and no key changes them, so
+// this is the normal case; the batch keeps a flag and only a set_state / nudge with non-zero end velocities
+// selects the general instantiation.  With ZV the two fields are neither read nor held, and the four velocity
+// combinations lose a multiply-add each; the results are bit-identical to the general code on zero inputs
+// (fma(c, 0, x) == x exactly).
+template <typename T, bool ZV = false> struct Prob {
+    static constexpr bool zero_vel = ZV;
+    T v0, v2;      // vel0X, vel2X (unused when ZV)
     T dx0, dx1;    // pos1X - pos0X, pos2X - pos1X
 };
+template <typename T, class P> __device__ __forceinline__ T seg0_m(const P &k, T v) { if constexpr (P::zero_vel) return T(-2) * v; else return fma_(T(-4), k.v0, T(-2) * v); }   // v0*-4 + v1*-2
+template <typename T, class P> __device__ __forceinline__ T seg0_n(const P &k, T v) { if constexpr (P::zero_vel) return T(4) * v; else return fma_(T(2), k.v0, T(4) * v); }      // v0*2 + v1*4
+template <typename T, class P> __device__ __forceinline__ T seg1_m(const P &k, T v) { if constexpr (P::zero_vel) return T(-4) * v; else return fma_(T(-4), v, T(-2) * k.v2); }   // segment 1: v0 = vel1, v1 = vel2
+template <typename T, class P> __device__ __forceinline__ T seg1_n(const P &k, T v) { if constexpr (P::zero_vel) return T(2) * v; else return fma_(T(2), v, T(4) * k.v2); }
 
 // End accelerations of both segments and their first derivatives at one (v, t0, t1).
 // index j: 0 = segment 0 initial, 1 = segment 0 final, 2 = segment 1 initial, 3 = segment 1 final
@@ -137,17 +148,15 @@ template <> struct CMap<3> { static constexpr int NC = 8; };   // onedpath_ip.cp
 template <> struct CMap<4> { static constexpr int NC = 4; };   // onedpath2_ip.cpp
 
 // accelerations only: enough for constraintsSatisfied (onedpath_ip.cpp:738-751)
-template <typename T>
-__device__ __forceinline__ void accel_values(const Prob<T> &k, T v, T t0, T t1, Acc<T> &e)
+template <typename T, class P>
+__device__ __forceinline__ void accel_values(const P &k, T v, T t0, T t1, Acc<T> &e)
 {
     const T r0 = rcp_(t0), r1 = rcp_(t1);
     e.r0 = r0;
     e.r1 = r1;
     const T u0 = k.dx0 * r0, u1 = k.dx1 * r1;                 // dX / t
-    const T m0 = fma_(T(-4), k.v0, T(-2) * v);                // v0*-4 + v1*-2   (segment 0: v1 = vel1)
-    const T n0 = fma_(T(2), k.v0, T(4) * v);                  // v0*2 + v1*4
-    const T m1 = fma_(T(-4), v, T(-2) * k.v2);                // segment 1: v0 = vel1, v1 = vel2
-    const T n1 = fma_(T(2), v, T(4) * k.v2);
+    const T m0 = seg0_m<T>(k, v), n0 = seg0_n<T>(k, v);       // segment 0: v1 = vel1
+    const T m1 = seg1_m<T>(k, v), n1 = seg1_n<T>(k, v);       // segment 1: v0 = vel1
     e.a[0] = fma_(T(6), u0, m0) * r0;
     e.a[1] = fma_(T(-6), u0, n0) * r0;
     e.a[2] = fma_(T(6), u1, m1) * r1;
@@ -155,15 +164,13 @@ __device__ __forceinline__ void accel_values(const Prob<T> &k, T v, T t0, T t1, 
 }
 
 // first derivatives, from the reciprocals already in e (dAdT, dAdV0/dAdV1 of :389-391, :430-432)
-template <typename T>
-__device__ __forceinline__ void accel_grads(const Prob<T> &k, T v, Acc<T> &e)
+template <typename T, class P>
+__device__ __forceinline__ void accel_grads(const P &k, T v, Acc<T> &e)
 {
     const T r0 = e.r0, r1 = e.r1;
     const T u0 = k.dx0 * r0, u1 = k.dx1 * r1;
-    const T m0 = fma_(T(-4), k.v0, T(-2) * v);
-    const T n0 = fma_(T(2), k.v0, T(4) * v);
-    const T m1 = fma_(T(-4), v, T(-2) * k.v2);
-    const T n1 = fma_(T(2), v, T(4) * k.v2);
+    const T m0 = seg0_m<T>(k, v), n0 = seg0_n<T>(k, v);
+    const T m1 = seg1_m<T>(k, v), n1 = seg1_n<T>(k, v);
     const T q0 = r0 * r0, q1 = r1 * r1;
     e.gt[0] = fma_(T(-12), u0, -m0) * q0;
     e.gt[1] = fma_(T(12), u0, -n0) * q0;
@@ -172,15 +179,13 @@ __device__ __forceinline__ void accel_grads(const Prob<T> &k, T v, Acc<T> &e)
 }
 
 // second derivatives (evalAccelSecondDerivInit / Final, onedpath_ip.cpp:394-411, 435-452)
-template <typename T>
-__device__ __forceinline__ void accel_hess(const Prob<T> &k, T v, const Acc<T> &e, T (&htt)[4], T (&htv)[4])
+template <typename T, class P>
+__device__ __forceinline__ void accel_hess(const P &k, T v, const Acc<T> &e, T (&htt)[4], T (&htv)[4])
 {
     const T r0 = e.r0, r1 = e.r1;
     const T u0 = k.dx0 * r0, u1 = k.dx1 * r1;
-    const T m0 = fma_(T(-4), k.v0, T(-2) * v);
-    const T n0 = fma_(T(2), k.v0, T(4) * v);
-    const T m1 = fma_(T(-4), v, T(-2) * k.v2);
-    const T n1 = fma_(T(2), v, T(4) * k.v2);
+    const T m0 = seg0_m<T>(k, v), n0 = seg0_n<T>(k, v);
+    const T m1 = seg1_m<T>(k, v), n1 = seg1_n<T>(k, v);
     const T q0 = r0 * r0, q1 = r1 * r1;
     const T c0 = q0 * r0, c1 = q1 * r1;
     htt[0] = fma_(T(36), u0, T(2) * m0) * c0;      // (36 dX/t - 8 v0 - 4 v1) / t^3
@@ -370,8 +375,8 @@ __device__ __forceinline__ void solve_arrow(T a, T b, T c, T d, T e, T rv, T r0,
 
 // ---- the Newton direction (onedpath_ip.cpp:812-887, condensed) --------------------------
 // In: point (v; e = values + grads there), multipliers, perturbation p.  Out: dx, d lam.
-template <typename T, int VARIANT>
-__device__ __forceinline__ void direction(const Prob<T> &k, const KParams<T> &kp, T v, const T (&lam)[CMap<VARIANT>::NC],
+template <typename T, int VARIANT, class P>
+__device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v, const T (&lam)[CMap<VARIANT>::NC],
                                           const Acc<T> &e, T p, T &dxv, T &dx0, T &dx1, T (&dl)[CMap<VARIANT>::NC])
 {
     const T L = kp.limit;
@@ -453,8 +458,8 @@ __device__ __forceinline__ void direction(const Prob<T> &k, const KParams<T> &kp
 // ---- one Newton step -------------------------------------------------------------------
 // In:  x = (v, t0, t1), lam, e = values + grads at x, gap = surrogate duality gap at x.
 // Out: the same at the new point (the caller recomputes the gap from e).
-template <typename T, int VARIANT>
-__device__ __forceinline__ void newton_step(const Prob<T> &k, const KParams<T> &kp, T gap,
+template <typename T, int VARIANT, class P>
+__device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
                                             T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], Acc<T> &e)
 {
     constexpr int NC = CMap<VARIANT>::NC;
@@ -463,7 +468,7 @@ __device__ __forceinline__ void newton_step(const Prob<T> &k, const KParams<T> &
     const bool feasible_here = all_satisfied<T, VARIANT>(e, L);
 
     T dxv, dx0, dx1, dl[NC];
-    direction<T, VARIANT>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
+    direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
 
     // -- fraction to the boundary on the multipliers (onedpath_ip.cpp:903-915) --
     T s = T(1);

@@ -17,6 +17,7 @@ struct BatchView {
     size_t n;              // problems
     int variant;           // 3 or 4
     int dtype;             // 0 = f64, 1 = f32
+    bool zero_end_vel;     // vel0X == vel2X == 0 for every problem (true after every init the reference has; see Prob in ip_core.h)
     int32_t *iters;        // gated Newton steps taken per problem
     uint32_t *status;      // RP_ST_* bits per problem
     uint16_t *order;       // scheduling permutation for the fused solve (k_order_tiles): tile-local indices

@@ -73,8 +73,8 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 // The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
 // STALL: compile the stall detector in (two more live registers); the tiled solve instantiates both
 // forms and picks by rp_params.stall_window, so the default (off) pays nothing for it.
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED>
-__device__ __forceinline__ void run_lane(const Prob<T> &pr, const KParams<T> &kp, int k, T tol, int max_iter,
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>>
+__device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open)
 {
@@ -95,7 +95,7 @@ __device__ __forceinline__ void run_lane(const Prob<T> &pr, const KParams<T> &kp
                 else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
             }
         }
-        newton_step<T, VARIANT>(pr, kp, gap, v, t0, t1, lam, e);
+        newton_step<T, VARIANT, P>(pr, kp, gap, v, t0, t1, lam, e);
         ++it;
         ++steps_here;
     }
@@ -112,7 +112,7 @@ __device__ __forceinline__ void run_lane(const Prob<T> &pr, const KParams<T> &kp
     }
 }
 
-template <typename T, int VARIANT, bool GATED>
+template <typename T, int VARIANT, bool GATED, bool ZV>
 __global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
 k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
          int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters)
@@ -139,15 +139,17 @@ k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
         T lam[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) lam[c] = f[(3 + c) * stride];
-        Prob<T> pr;
+        Prob<T, ZV> pr;
         {
             const T p0 = f[(CB + 0) * stride], p1 = f[(CB + 2) * stride], p2 = f[(CB + 3) * stride];
-            pr.v0 = f[(CB + 1) * stride];
-            pr.v2 = f[(CB + 4) * stride];
+            if constexpr (!ZV) {
+                pr.v0 = f[(CB + 1) * stride];
+                pr.v2 = f[(CB + 4) * stride];
+            }
             pr.dx0 = p1 - p0;
             pr.dx1 = p2 - p1;
         }
-        run_lane<T, VARIANT, GATED>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, GATED, GATED, Prob<T, ZV>>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
         if (GATED) {
             iters[i] = it;
             status[i] = st;
@@ -182,7 +184,7 @@ k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
 // next state streams in under the arithmetic of the current one.
 template <typename T, int NF> struct LaneState { T f[NF]; };
 
-template <typename T, int VARIANT>
+template <typename T, int VARIANT, bool ZV>
 __global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
 k_newton_stream(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
 {
@@ -194,7 +196,8 @@ k_newton_stream(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
     LaneState<T, NF> cur, nxt;
     if (i >= n) return;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) cur.f[f] = base[(size_t)f * stride + i];
+    for (int f = 0; f < NF; ++f)
+        if (!(ZV && (f == CB + 1 || f == CB + 4))) cur.f[f] = base[(size_t)f * stride + i];     // ZV: end velocities not read
     for (;;) {
         // The prefetch is unconditional (the last round re-reads its own problem): a conditional
         // load makes the compiler's s_waitcnt pass assume the worst at the join and drain the
@@ -203,20 +206,23 @@ k_newton_stream(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
         const bool have_next = inext < n;
         const size_t src = have_next ? inext : i;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) nxt.f[f] = base[(size_t)f * stride + src];
+        for (int f = 0; f < NF; ++f)
+            if (!(ZV && (f == CB + 1 || f == CB + 4))) nxt.f[f] = base[(size_t)f * stride + src];
         T v = cur.f[0], t0 = cur.f[1], t1 = cur.f[2];
         T lam[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) lam[c] = cur.f[3 + c];
-        Prob<T> pr;
-        pr.v0 = cur.f[CB + 1];
-        pr.v2 = cur.f[CB + 4];
+        Prob<T, ZV> pr;
+        if constexpr (!ZV) {
+            pr.v0 = cur.f[CB + 1];
+            pr.v2 = cur.f[CB + 4];
+        }
         pr.dx0 = cur.f[CB + 2] - cur.f[CB + 0];
         pr.dx1 = cur.f[CB + 3] - cur.f[CB + 2];
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
         T *f = base + i;
         f[0 * stride] = v;
         f[1 * stride] = t0;
@@ -289,7 +295,7 @@ k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__r
     }
 }
 
-template <typename T, int VARIANT, bool STALL>
+template <typename T, int VARIANT, bool STALL, bool ZV>
 __global__ void __launch_bounds__(kBlock, RP_TILED_WAVES)
 k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T tol, int max_iter,
               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
@@ -330,19 +336,21 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T to
             T lam[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) lam[c] = sm[3 + c][j];
-            Prob<T> pr;     // constants: a gather inside the tile's 4 KiB window of each field, once per problem
+            Prob<T, ZV> pr;     // constants: a gather inside the tile's 4 KiB window of each field, once per problem
             {
                 const T *g = base + first + j;
                 const T q0 = g[(size_t)(CB + 0) * stride], q1 = g[(size_t)(CB + 2) * stride], q2 = g[(size_t)(CB + 3) * stride];
-                pr.v0 = g[(size_t)(CB + 1) * stride];
-                pr.v2 = g[(size_t)(CB + 4) * stride];
+                if constexpr (!ZV) {
+                    pr.v0 = g[(size_t)(CB + 1) * stride];
+                    pr.v2 = g[(size_t)(CB + 4) * stride];
+                }
                 pr.dx0 = q1 - q0;
                 pr.dx1 = q2 - q1;
             }
             int it = s_it[j];
             uint32_t st = s_st[j];
             bool still_open = false;
-            run_lane<T, VARIANT, true, STALL>(pr, kp, max_iter > 0 ? max_iter : 1, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+            run_lane<T, VARIANT, true, STALL, Prob<T, ZV>>(pr, kp, max_iter > 0 ? max_iter : 1, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
             open_any = open_any || still_open;
             sm[0][j] = v;
             sm[1][j] = t0;
@@ -631,6 +639,13 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
 
 }  // namespace
 
+// the three Newton kernels are also instantiated for "end velocities are zero" (BatchView::zero_end_vel)
+#define RP_DISPATCH_Z(b, ...)                                             \
+    do {                                                                  \
+        if ((b).zero_end_vel) { constexpr bool Z = true; RP_DISPATCH(b, __VA_ARGS__); }   \
+        else                  { constexpr bool Z = false; RP_DISPATCH(b, __VA_ARGS__); }  \
+    } while (0)
+
 hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStream_t stream)
 {
     if (k < 0 || b.n == 0) return hipSuccess;     // k == 0: load/store only (bandwidth probe, see rp_batch_step)
@@ -642,8 +657,8 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     const unsigned cap = grid_env ? (unsigned)atoi(grid_env) : (k <= 2 ? 512u : 2048u);
     unsigned grid = grid_for(b.n);
     if (grid > cap) grid = cap;
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_newton_stream<T, V>), dim3(grid), dim3(kBlock), 0, stream,
-                                       (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
+    RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton_stream<T, V, Z>), dim3(grid), dim3(kBlock), 0, stream,
+                                         (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
     return hipGetLastError();
 }
 
@@ -655,20 +670,20 @@ hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double g
     // 512 problems): small batches take the plain one-problem-per-lane kernel.
     static const bool no_tiled = getenv("RP_NO_TILED") != nullptr;     // A/B switch for tuning
     if (no_tiled || b.n < (size_t)kTile * 512) {
-        RP_DISPATCH(b, hipLaunchKernelGGL((k_newton<T, V, true>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                           (T *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
-                                           (T)gap_tol, max_iter, b.iters, b.status, b.counters));
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                             (T *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
+                                             (T)gap_tol, max_iter, b.iters, b.status, b.counters));
         return hipGetLastError();
     }
     const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
     if (hp.stall_window > 0)
-        RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_tiled<T, V, true>), dim3(grid), dim3(kBlock), 0, stream,
-                                           (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
-                                           b.iters, b.status, b.counters, (const uint16_t *)b.order));
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, true, Z>), dim3(grid), dim3(kBlock), 0, stream,
+                                             (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
+                                             b.iters, b.status, b.counters, (const uint16_t *)b.order));
     else
-        RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_tiled<T, V, false>), dim3(grid), dim3(kBlock), 0, stream,
-                                           (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
-                                           b.iters, b.status, b.counters, (const uint16_t *)b.order));
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, false, Z>), dim3(grid), dim3(kBlock), 0, stream,
+                                             (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
+                                             b.iters, b.status, b.counters, (const uint16_t *)b.order));
     return hipGetLastError();
 }
 
@@ -685,9 +700,9 @@ hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double 
 {
     if (b.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(kShards), 0, stream, b.counters);
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_newton<T, V, true>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                       (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
-                                       b.iters, b.status, b.counters));
+    RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                         (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
+                                         b.iters, b.status, b.counters));
     return hipGetLastError();
 }
 

@@ -151,6 +151,7 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     b->view.variant = variant;
     b->view.dtype = dtype;
     b->view.stride = (n + 255) / 256 * 256;
+    b->view.zero_end_vel = true;       // the state starts all-zero
     const size_t fields = (size_t)rp::state_len(variant);
 
     hipError_t e = hipSuccess;
@@ -252,6 +253,7 @@ int rp_batch_init_default(rp_batch *b)
     for (int i = 0; i < m; ++i) s[3 + i] = 1.0;
     s[3 + m + 0] = 0.0; s[3 + m + 1] = 0.0; s[3 + m + 2] = 200.0; s[3 + m + 3] = 400.0; s[3 + m + 4] = 0.0;
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
+    b->view.zero_end_vel = true;
     return reset_progress(b);
 }
 
@@ -264,6 +266,7 @@ int rp_batch_init_stuck(rp_batch *b)
                           5.45948e-07, 0.00310769, 3.49109e-08, 0.00281523, 8.39344e-07, 1.76937e-06, 0.0187559, 8.42414e-07,
                           0.0, 0.0, 350.0, 400.0, 0.0};
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
+    b->view.zero_end_vel = true;
     return reset_progress(b);
 }
 
@@ -272,6 +275,7 @@ int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double
     RP_NEED(b);
     if (!d_pos0 || !d_pos1 || !d_pos2) return fail(RP_ERR_INVALID, "null position array");
     RP_HIP(rp::launch_init_feasible(b->view, b->params, d_pos0, d_pos1, d_pos2, b->stream));
+    b->view.zero_end_vel = true;       // the feasible-start rule sets vel0 = vel2 = 0
     return reset_progress(b);
 }
 
@@ -296,7 +300,13 @@ int rp_batch_set_state(rp_batch *b, const double *aos)
     if (!aos) return fail(RP_ERR_INVALID, "null state array");
     int st = need_aos(b);
     if (st != RP_OK) return st;
-    const size_t bytes = b->view.n * rp::state_len(b->view.variant) * sizeof(double);
+    const size_t M = (size_t)rp::state_len(b->view.variant), bytes = b->view.n * M * sizeof(double);
+    {   // which instantiation the Newton kernels may use: are all end velocities zero?  (NaN counts as non-zero)
+        const size_t iv0 = 3 + rp::num_constraints(b->view.variant) + 1, iv2 = iv0 + 3;
+        bool zero = true;
+        for (size_t i = 0; i < b->view.n && zero; ++i) zero = (aos[i * M + iv0] == 0.0) && (aos[i * M + iv2] == 0.0);
+        b->view.zero_end_vel = zero;
+    }
     RP_HIP(hipMemcpyAsync(b->d_aos, aos, bytes, hipMemcpyHostToDevice, b->stream));
     RP_HIP(rp::launch_aos_to_soa(b->view, b->d_aos, b->stream));
     st = reset_progress(b);
@@ -323,6 +333,10 @@ int rp_batch_nudge(rp_batch *b, int var_index, double delta)
     RP_NEED(b);
     if (var_index < 0 || var_index >= rp::state_len(b->view.variant)) return fail(RP_ERR_INVALID, "variable index %d out of range", var_index);
     RP_HIP(rp::launch_nudge(b->view, var_index, delta, b->stream));
+    {
+        const int iv0 = 3 + rp::num_constraints(b->view.variant) + 1, iv2 = iv0 + 3;
+        if ((var_index == iv0 || var_index == iv2) && delta != 0.0) b->view.zero_end_vel = false;
+    }
     return RP_OK;
 }
 

@@ -439,3 +439,39 @@ def test_sharded_cpp_host_with_rccl_on_one_device():
     # asking for more devices than exist is refused, not faked
     bad = subprocess.run([exe, "--gpus", "64", "--n", "128", "--keys", "s"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "visible" in bad.stderr
+
+
+def test_zero_end_velocity_specialisation_is_bit_identical_to_the_general_kernels():
+    # Every init the reference has leaves vel0X = vel2X = 0, and the kernels are instantiated for that case
+    # (two fields not read, four multiply-adds fewer per evaluation).  A +1/-1 nudge of vel0X leaves the values at
+    # zero but clears the batch's flag, i.e. selects the general instantiation: results must not differ by a bit.
+    n = 512 * 512 + 100
+    p0, p1, p2 = rp.problems.generate(321, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0, p1, p2)
+        b.nudge(12, 1.0); b.nudge(12, -1.0)           # vel0X (index 12 of enum V)
+        assert np.array_equal(a.get_state(), b.get_state())
+        a.step(3); b.step(3)                           # streaming kernel
+        assert np.array_equal(a.get_state(), b.get_state())
+        a.solve(1e-8, 200, 0); b.solve(1e-8, 200, 0)   # tiled solve
+        assert np.array_equal(a.get_state(), b.get_state()) and np.array_equal(a.get_iters()[0], b.get_iters()[0])
+        a.set_problems(p0, p1, p2); b.set_problems(p0, p1, p2)
+        b.nudge(15, 2.0); b.nudge(15, -2.0)            # vel2X
+        a.solve(1e-8, 200, 3); b.solve(1e-8, 200, 3)   # plain gated kernel
+        assert np.array_equal(a.get_state(), b.get_state())
+
+
+def test_non_zero_end_velocities_against_oracle(oracle, g3):
+    m = 4096
+    st = g3["init"][:m].copy()
+    st[:, 12] = np.linspace(-3.0, 3.0, m)
+    st[:, 15] = np.linspace(2.0, -2.0, m)
+    exp = st.copy()
+    oracle.batch_steps(3, exp, 4)
+    with rp.Batch(m) as c:
+        c.set_state(st)
+        c.step(4)
+        out = c.get_state()
+    assert serr(out[:, :3], exp[:, :3]) < TOL
+    assert np.array_equal(out[:, 11:], st[:, 11:])
