@@ -133,7 +133,14 @@ template <typename T, class P> __device__ __forceinline__ T seg1_n(const P &k, T
 template <typename T> struct Acc {
     T r0, r1;      // 1/t0, 1/t1
     T a[4];
-    T gt[4];       // d a_j / d t_seg(j)
+    T gt[4];       // d a_j / d t_seg(j)   (not carried from step to step: rebuilt by accel_grads, see newton_step)
+};
+// What a lane carries from one step to the next: the reciprocals and the four accelerations.  The time
+// derivatives are rebuilt at the start of the step (14 flop): eight registers that are then free in the
+// residual backtracking loop, the register peak of the step.
+template <typename T> struct AccCarry {
+    T r0, r1;
+    T a[4];
 };
 
 // d a_j / d vel1: dAdV1 of segment 0's ends (-2/t0, 4/t0), dAdV0 of segment 1's ends (-4/t1, 2/t1)
@@ -201,8 +208,8 @@ __device__ __forceinline__ void accel_hess(const P &k, T v, const Acc<T> &e, T (
 // ---- constraints built on the accelerations -------------------------------------------
 // F3 (evalConstraint0..7, onedpath_ip.cpp:454-625): i -> accel i/2, even i: -a - L, odd i: a - L.
 // F4 (evalConstraint0..3, onedpath2_ip.cpp:414-511): i -> accel i, (a^2 - L^2)/2.
-template <typename T, int VARIANT>
-__device__ __forceinline__ T c_value(int i, const Acc<T> &e, T L)
+template <typename T, int VARIANT, class A = Acc<T>>
+__device__ __forceinline__ T c_value(int i, const A &e, T L)
 {
     if constexpr (VARIANT == 3) {
         const T a = e.a[i >> 1];
@@ -235,8 +242,8 @@ template <int VARIANT> __device__ __forceinline__ constexpr int c_segment(int i)
 // constraintsSatisfied (onedpath_ip.cpp:738-751): false iff some error > 0 (NaN passes, as there).
 // F3: -a - L > 0 or a - L > 0  <=>  |a| > L exactly (a floating-point difference has the sign of
 // the exact difference), so one compare per acceleration.
-template <typename T, int VARIANT>
-__device__ __forceinline__ bool all_satisfied(const Acc<T> &e, T L)
+template <typename T, int VARIANT, class A = Acc<T>>
+__device__ __forceinline__ bool all_satisfied(const A &e, T L)
 {
     bool ok = true;
     if constexpr (VARIANT == 3) {
@@ -244,18 +251,18 @@ __device__ __forceinline__ bool all_satisfied(const Acc<T> &e, T L)
         for (int j = 0; j < 4; ++j) ok = ok && !(abs_(e.a[j]) > L);
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ok = ok && !(c_value<T, 4>(i, e, L) > T(0));
+        for (int i = 0; i < 4; ++i) ok = ok && !(c_value<T, 4, A>(i, e, L) > T(0));
     }
     return ok;
 }
 
 // surrogateDualityGap (onedpath_ip.cpp:794-808)
-template <typename T, int VARIANT>
-__device__ __forceinline__ T duality_gap(const Acc<T> &e, const T (&lam)[CMap<VARIANT>::NC], T L)
+template <typename T, int VARIANT, class A = Acc<T>>
+__device__ __forceinline__ T duality_gap(const A &e, const T (&lam)[CMap<VARIANT>::NC], T L)
 {
     T mu = T(0);
 #pragma unroll
-    for (int i = 0; i < CMap<VARIANT>::NC; ++i) mu = fma_(-c_value<T, VARIANT>(i, e, L), lam[i], mu);
+    for (int i = 0; i < CMap<VARIANT>::NC; ++i) mu = fma_(-c_value<T, VARIANT, A>(i, e, L), lam[i], mu);
     return mu;
 }
 
@@ -456,19 +463,28 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
 }
 
 // ---- one Newton step -------------------------------------------------------------------
-// In:  x = (v, t0, t1), lam, e = values + grads at x, gap = surrogate duality gap at x.
-// Out: the same at the new point (the caller recomputes the gap from e).
+// In:  x = (v, t0, t1), lam, c = reciprocals + accelerations at x, gap = surrogate duality gap at x.
+// Out: the same at the new point (the caller recomputes the gap from c).
 template <typename T, int VARIANT, class P>
 __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
-                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], Acc<T> &e)
+                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T> &c)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     const T L = kp.limit;
     const T p = gap * kp.inv_mu_den;                      // onedpath_ip.cpp:812
-    const bool feasible_here = all_satisfied<T, VARIANT>(e, L);
 
-    T dxv, dx0, dx1, dl[NC];
-    direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
+    T dxv, dx0, dx1, dl[NC], r0n;
+    bool feasible_here;
+    {
+        Acc<T> e;
+        e.r0 = c.r0; e.r1 = c.r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e.a[j] = c.a[j];
+        accel_grads(k, v, e);
+        feasible_here = all_satisfied<T, VARIANT>(e, L);
+        direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
+        r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);      // onedpath_ip.cpp:932
+    }
 
     // -- fraction to the boundary on the multipliers (onedpath_ip.cpp:903-915) --
     T s = T(1);
@@ -502,9 +518,9 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     }
 
     // -- backtrack until the residual decreases (onedpath_ip.cpp:932-945) --
-    const T r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);
-    bool accepted_eval = false;    // et = values + grads at the point the loop broke on
-    bool accepted_same = false;    // ... which is bitwise the current point
+    // The loop works in `et` only.  When a trial point is bitwise x, the evaluation at x is rebuilt in `et`
+    // from the carried reciprocals and accelerations -- bit for bit what the step started from.
+    bool accepted = false;         // et = values at the point the loop broke on
     for (int it = 0; it < kp.max_bt; ++it) {
         tv = fma_(dxv, s, v);
         tt0 = fma_(dx0, s, t0);
@@ -515,7 +531,15 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
             bool same_l = true;     // only worth asking once the step no longer moves x (stalled regime)
 #pragma unroll
             for (int i = 0; i < NC; ++i) same_l = same_l && (fma_(dl[i], s, lam[i]) == lam[i]);
-            rn = same_l ? r0n : residual_norm<T, VARIANT, true>(e, lam, dl, s, p, L);
+            et.r0 = c.r0; et.r1 = c.r1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) et.a[j] = c.a[j];
+            if (same_l) {
+                rn = r0n;
+            } else {
+                accel_grads(k, v, et);
+                rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
+            }
         } else {
             if (!et_valid) accel_values(k, tv, tt0, tt1, et);
             accel_grads(k, tv, et);
@@ -523,8 +547,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         }
         et_valid = false;
         if (rn <= r0n * (T(1) - kp.armijo * s)) {
-            accepted_eval = !same_x;
-            accepted_same = same_x;
+            accepted = true;
             break;
         }
         s *= kp.backtrack;
@@ -537,13 +560,10 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 #pragma unroll
     for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
 
-    if (accepted_eval) {
-        e = et;
-    } else if (!accepted_same) {
-        // loop ran out of halvings: the accepted s was never evaluated
-        accel_values(k, v, t0, t1, e);
-        accel_grads(k, v, e);
-    }
+    if (!accepted) accel_values(k, v, t0, t1, et);     // the loop ran out of halvings: its last s was never evaluated
+    c.r0 = et.r0; c.r1 = et.r1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c.a[j] = et.a[j];
 }
 
 }  // namespace rp

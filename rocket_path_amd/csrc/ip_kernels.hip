@@ -67,7 +67,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 #define RP_NEWTON_WAVES 2     // minimum waves per SIMD the register allocator must leave room for
 #endif
 #ifndef RP_TILED_WAVES
-#define RP_TILED_WAVES 2
+#define RP_TILED_WAVES 3     // the tiled solve fits 168 VGPRs and 48 KiB of LDS per block: three blocks per CU
 #endif
 
 // The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
@@ -78,15 +78,20 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open)
 {
-    Acc<T> e;
-    accel_values(pr, v, t0, t1, e);
-    accel_grads(pr, v, e);
+    AccCarry<T> e;      // reciprocals + accelerations at the current point, carried from step to step
+    {
+        Acc<T> e0;
+        accel_values(pr, v, t0, t1, e0);
+        e.r0 = e0.r0; e.r1 = e0.r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e.a[j] = e0.a[j];
+    }
 
     bool done = false;
     T best_gap = T(3.0e38);      // stall detector state (off unless kp.stall_window > 0)
     int since_best = 0;
     for (int s = 0; s < k; ++s) {
-        const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
+        const T gap = duality_gap<T, VARIANT, AccCarry<T>>(e, lam, kp.limit);
         if (GATED) {
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
             if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; break; }
@@ -101,13 +106,13 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     }
     if (GATED) {
         if (!done) {   // settle the status now so the host knows whether to launch again
-            const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
+            const T gap = duality_gap<T, VARIANT, AccCarry<T>>(e, lam, kp.limit);
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; }
             else if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; }
         }
         st &= ~(RP_ST_NONFINITE | RP_ST_INFEASIBLE);
         if (!(finite_(v) && finite_(t0) && finite_(t1))) st |= RP_ST_NONFINITE;
-        if (!all_satisfied<T, VARIANT>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
+        if (!all_satisfied<T, VARIANT, AccCarry<T>>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
         still_open = !done;
     }
 }
