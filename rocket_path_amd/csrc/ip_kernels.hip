@@ -300,17 +300,19 @@ k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__r
     }
 }
 
-template <typename T, int VARIANT, bool STALL, bool ZV>
+// GATED = true: the fused gated solve.  GATED = false: k ungated steps per problem through the same tile
+// staging (for k >= 3 the arithmetic dominates, and this is the form that fits three waves per SIMD).
+template <typename T, int VARIANT, bool GATED, bool STALL, bool ZV>
 __global__ void __launch_bounds__(kBlock, RP_TILED_WAVES)
-k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T tol, int max_iter,
+k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
               const uint16_t *__restrict__ order)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
     __shared__ T sm[CB][kTile];            // the mutable fields only; the five constants are read once per problem
-    __shared__ int32_t s_it[kTile];
-    __shared__ uint32_t s_st[kTile];
+    __shared__ int32_t s_it[GATED ? kTile : 1];
+    __shared__ uint32_t s_st[GATED ? kTile : 1];
 
     const int tid = threadIdx.x;
     const size_t first = (size_t)blockIdx.x * kTile;
@@ -320,7 +322,8 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T to
 #pragma unroll
     for (int f = 0; f < CB; ++f)
         for (int j = tid; j < count; j += kBlock) sm[f][j] = base[(size_t)f * stride + first + j];
-    for (int j = tid; j < count; j += kBlock) { s_it[j] = iters[first + j]; s_st[j] = status[first + j]; }
+    if (GATED)
+        for (int j = tid; j < count; j += kBlock) { s_it[j] = iters[first + j]; s_st[j] = status[first + j]; }
     // this thread's two scheduled problems: sorted chunks `wave` and `7 - wave`
     const int wave = tid >> 6, lane = tid & 63;
     int mine[2];
@@ -336,7 +339,9 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T to
 #pragma unroll 1
     for (int round = 0; round < 2; ++round) {
         const int j = mine[round];
-        if (j >= 0 && (s_st[j] & (RP_ST_CONVERGED | RP_ST_MAXITER | RP_ST_STALLED)) == 0) {
+        bool live = j >= 0;
+        if (GATED && live) live = (s_st[j] & (RP_ST_CONVERGED | RP_ST_MAXITER | RP_ST_STALLED)) == 0;
+        if (live) {
             T v = sm[0][j], t0 = sm[1][j], t1 = sm[2][j];
             T lam[NC];
 #pragma unroll
@@ -352,18 +357,17 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T to
                 pr.dx0 = q1 - q0;
                 pr.dx1 = q2 - q1;
             }
-            int it = s_it[j];
-            uint32_t st = s_st[j];
+            int it = GATED ? s_it[j] : 0;
+            uint32_t st = GATED ? s_st[j] : 0u;
             bool still_open = false;
-            run_lane<T, VARIANT, true, STALL, Prob<T, ZV>>(pr, kp, max_iter > 0 ? max_iter : 1, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+            run_lane<T, VARIANT, GATED, STALL, Prob<T, ZV>>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
             open_any = open_any || still_open;
             sm[0][j] = v;
             sm[1][j] = t0;
             sm[2][j] = t1;
 #pragma unroll
             for (int c = 0; c < NC; ++c) sm[3 + c][j] = lam[c];
-            s_it[j] = it;
-            s_st[j] = st;
+            if (GATED) { s_it[j] = it; s_st[j] = st; }
         }
     }
     __syncthreads();
@@ -372,14 +376,15 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp, T to
 #pragma unroll
     for (int f = 0; f < CB; ++f)
         for (int j = tid; j < count; j += kBlock) base[(size_t)f * stride + first + j] = sm[f][j];
-    for (int j = tid; j < count; j += kBlock) { iters[first + j] = s_it[j]; status[first + j] = s_st[j]; }
-
-    const unsigned long long open_mask = __ballot(open_any);
-    const int steps_wave = wave_sum<int>(steps_here);
-    if (lane == 0) {
-        const unsigned shard = (blockIdx.x * (kBlock / 64) + wave) & (kShards - 1);
-        if (open_mask) atomicAdd(&counters[shard], (unsigned long long)__popcll(open_mask));
-        if (steps_wave) atomicAdd(&counters[kShards + shard], (unsigned long long)steps_wave);
+    if (GATED) {
+        for (int j = tid; j < count; j += kBlock) { iters[first + j] = s_it[j]; status[first + j] = s_st[j]; }
+        const unsigned long long open_mask = __ballot(open_any);
+        const int steps_wave = wave_sum<int>(steps_here);
+        if (lane == 0) {
+            const unsigned shard = (blockIdx.x * (kBlock / 64) + wave) & (kShards - 1);
+            if (open_mask) atomicAdd(&counters[shard], (unsigned long long)__popcll(open_mask));
+            if (steps_wave) atomicAdd(&counters[kShards + shard], (unsigned long long)steps_wave);
+        }
     }
 }
 
@@ -655,11 +660,20 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
 {
     if (k < 0 || b.n == 0) return hipSuccess;     // k == 0: load/store only (bandwidth probe, see rp_batch_step)
     // resident set: 256 CUs x 2 blocks (2 waves per SIMD); larger batches are walked with that stride
-    // k <= 2 is memory-bound: grid = the resident set (256 CUs x 2 blocks) so that each lane walks 8 problems at
-    // 1 Mi and its register prefetch hides the HBM latency.  Larger k is arithmetic-bound and prefers more, shorter
-    // blocks (measured at k = 12: 512 -> 47.1, 1024 -> 48.2, 2048 -> 49.5 G steps/s; at k = 1 2048 costs 25 %).
-    static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override
-    const unsigned cap = grid_env ? (unsigned)atoi(grid_env) : (k <= 2 ? 512u : 2048u);
+    // k <= 2 is memory-bound: the streaming kernel, grid = the resident set (256 CUs x 2 blocks) so that each lane
+    // walks 8 problems at 1 Mi and its register prefetch hides the HBM latency.  Larger k is arithmetic-bound: there
+    // the second register set of the prefetch only costs occupancy, so k >= 3 on a batch large enough to fill the
+    // chip with 512-problem tiles runs the tiled kernel, ungated (168 VGPRs with zero end velocities: 3 waves per SIMD).
+    static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override: forces the streaming kernel
+    if (k >= 3 && !grid_env && b.n >= (size_t)kTile * 512) {
+        const unsigned tiles = (unsigned)((b.n + kTile - 1) / kTile);
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, false, false, Z>), dim3(tiles), dim3(kBlock), 0, stream,
+                                             (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), T(0), 0,
+                                             (int32_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr,
+                                             (const uint16_t *)b.order));
+        return hipGetLastError();
+    }
+    const unsigned cap = grid_env ? (unsigned)atoi(grid_env) : 512u;
     unsigned grid = grid_for(b.n);
     if (grid > cap) grid = cap;
     RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton_stream<T, V, Z>), dim3(grid), dim3(kBlock), 0, stream,
@@ -682,13 +696,13 @@ hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double g
     }
     const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
     if (hp.stall_window > 0)
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, true, Z>), dim3(grid), dim3(kBlock), 0, stream,
-                                             (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
-                                             b.iters, b.status, b.counters, (const uint16_t *)b.order));
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, true, true, Z>), dim3(grid), dim3(kBlock), 0, stream,
+                                             (T *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
+                                             (T)gap_tol, max_iter, b.iters, b.status, b.counters, (const uint16_t *)b.order));
     else
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, false, Z>), dim3(grid), dim3(kBlock), 0, stream,
-                                             (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
-                                             b.iters, b.status, b.counters, (const uint16_t *)b.order));
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, true, false, Z>), dim3(grid), dim3(kBlock), 0, stream,
+                                             (T *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
+                                             (T)gap_tol, max_iter, b.iters, b.status, b.counters, (const uint16_t *)b.order));
     return hipGetLastError();
 }
 
