@@ -260,15 +260,18 @@ def main():
 
     # The fused solve is fp64-ALU bound, so next to the (algorithmic) HBM roofline the same launch is priced against
     # the fp64 vector peak: flop per Newton step from the rocprofv3 SQ counters of profiles/r1_sq_counters.json
-    # (240 FMA x 2 + 100 MUL + 44 ADD + 19 RCP per lane-step of the 12-step fused kernel).
+    # (2 x FMA + MUL + ADD + RCP wave-instructions of the ungated 12-step launch, per lane-step).
     FLOP_PER_STEP, FP64_PEAK_TFLOPS = 643.0, 78.6
+    try:
+        FLOP_PER_STEP = float(json.load(open(os.path.join(ROOT, "profiles", "r1_sq_counters.json")))["_flop_per_newton_step"])
+    except Exception:
+        pass
     tflops = FLOP_PER_STEP * steps_per_launch / (kernel_ms * 1e-3) / 1e12
     line["compute_roofline"] = {"bound": "fp64 vector ALU", "flop_per_newton_step": FLOP_PER_STEP, "achieved": tflops,
                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
-                                "note": "493 VALU instructions per step, 403 of them fp64; measured issue cost 2.1 ns per fp64 "
-                                        "wave-instruction per SIMD (profiles/probes/valu_probe.hip) => 1.03 us of pure issue per "
-                                        "wave-step against 1.4 us achieved; idle lane-steps of the gated solve (~10 %) are not "
-                                        "counted as flops"}
+                                "note": "about 490 VALU instructions per step, 400 of them fp64; measured issue cost 2.1 ns per fp64 "
+                                        "wave-instruction per SIMD (profiles/probes/valu_probe.hip); idle lane-steps of the gated "
+                                        "solve (~10 %) are not counted as flops"}
 
     if not args.no_extras:
         # (a) one launch per Newton step: the HBM-streaming form of the same step (216 B really move per step).

@@ -48,9 +48,11 @@ for k in fetch:
     wr = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
     out[name] = {"FETCH_SIZE_KiB": fetch[k].get("FETCH_SIZE"), "WRITE_SIZE_KiB": write.get(k, {}).get("WRITE_SIZE"),
                  "read_bytes_corrected": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
-if "k_solve_tiled<double, 3>" in out:
-    out["k_solve_tiled_f3_f64"] = dict(out["k_solve_tiled<double, 3>"],
-                                       expected="(16x8 + 4 + 4 + 2) B read + (11x8 + 4 + 4) B written per problem = 144.7 + 100.7 MB at n = 1,048,576")
+gated = [k for k in out if k.startswith("k_solve_tiled<double, 3, true")]
+if gated:
+    out["k_solve_tiled_f3_f64"] = dict(out[gated[0]], kernel=gated[0],
+                                       expected="zero-end-velocity instantiation: (14x8 + 4 + 4 + 2) B read + (11x8 + 4 + 4) B written "
+                                                "per problem = 127.9 + 100.7 MB at n = 1,048,576")
 json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)       # read by bench.py
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag), "w"), indent=1)
 
@@ -64,6 +66,18 @@ for name, c in sq.items():
     if "SQ_WAVES" in c and "SQ_INSTS_VALU" in c:
         c["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
         c["valu_busy_per_wave_cycle"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+# flop per lane-step from the ungated 12-step launch of pmc_probe.py (1 Mi problems x 12 steps, every lane active):
+# SQ_INSTS_VALU_* count wave-instructions; x 64 lanes / (12 * 2^20 lane-steps)
+flop = None
+for name, c in sq.items():
+    if name.startswith("k_solve_tiled<double, 3, false") and "SQ_INSTS_VALU_FMA_F64" in c:
+        lane_steps = 12.0 * (1 << 20)
+        c["flop_per_lane_step"] = 64.0 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]
+                                          + c["SQ_INSTS_VALU_TRANS_F64"]) / lane_steps
+        c["valu_insts_per_wave_step"] = 64.0 * c["SQ_INSTS_VALU"] / lane_steps
+        flop = c["flop_per_lane_step"]
+if flop is not None:
+    sq["_flop_per_newton_step"] = flop
 json.dump({"_method": "rocprofv3 --pmc <SQ counters> -- python3 profiles/pmc_probe.py (1 Mi problems: 12 fused ungated steps, "
                       "then one fused gated solve); SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles", **sq},
           open(os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag), "w"), indent=1)
