@@ -302,8 +302,10 @@ k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__r
 
 // GATED = true: the fused gated solve.  GATED = false: k ungated steps per problem through the same tile
 // staging (for k >= 3 the arithmetic dominates, and this is the form that fits three waves per SIMD).
+// Only the default instantiations (zero end velocities, stall detector off) fit 168 VGPRs without spilling; the
+// others are held to two waves per SIMD instead (any scratch makes the launch time erratic).
 template <typename T, int VARIANT, bool GATED, bool STALL, bool ZV>
-__global__ void __launch_bounds__(kBlock, RP_TILED_WAVES)
+__global__ void __launch_bounds__(kBlock, (STALL || !ZV) ? 2 : RP_TILED_WAVES)
 k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
               const uint16_t *__restrict__ order)
