@@ -475,3 +475,18 @@ def test_non_zero_end_velocities_against_oracle(oracle, g3):
         out = c.get_state()
     assert serr(out[:, :3], exp[:, :3]) < TOL
     assert np.array_equal(out[:, 11:], st[:, 11:])
+
+
+def test_tiled_ungated_steps_equal_streamed_single_steps_bitwise():
+    # k >= 3 on a large batch runs the tiled kernel (ungated), k = 1 the streaming kernel: same arithmetic, same bits
+    n = 512 * 512 + 77
+    p0, p1, p2 = rp.problems.generate(2025, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0, p1, p2)
+        a.step(5)
+        for _ in range(5):
+            b.step(1)
+        assert np.array_equal(a.get_state(), b.get_state())
+        it, _ = a.get_iters()
+        assert np.all(it == 5)
