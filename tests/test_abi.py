@@ -109,3 +109,14 @@ def test_plugin_compiles_against_the_reference_problem_header(tmp_path):
                         "-I", os.path.join(ROOT, "include"), str(src), os.path.join(host, "batched_problem.cpp")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.skipif(rp.device_count() > 0, reason="a GPU is present")
+def test_bench_refuses_to_run_without_a_gpu():
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no HIP device" in (r.stderr + r.stdout)
+    assert "{" not in r.stdout          # no JSON line is ever printed from a CPU run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one process per GPU" in (r.stderr + r.stdout)
