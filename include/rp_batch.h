@@ -51,6 +51,12 @@ typedef enum {
 #define RP_VARIANT_F4 4
 #define RP_DTYPE_F64 0
 #define RP_DTYPE_F32 1
+/* fp32 state in HBM (the traffic of RP_DTYPE_F32: 76 B per F4 step), fp64 arithmetic in registers; the state is
+ * rounded to fp32 after every step.  One step from an fp32 state then agrees with the fp64 reference step from the
+ * same state to fp32 rounding (6e-8 relative) for every problem, where pure fp32 arithmetic cannot: its Armijo test
+ * (onedpath_ip.cpp:941) needs a relative residual decrease of 0.01 s, below fp32 resolution for s < 1e-5, and its 3x3
+ * solve loses cond(K) * 6e-8 -- see DESIGN.md section 4, "Single precision". */
+#define RP_DTYPE_F32_STATE 2
 
 /* Per-problem status bits (new; the reference has no error reporting). */
 #define RP_ST_CONVERGED 1u  /* gap < tol seen at a gate check */
@@ -108,6 +114,9 @@ RP_API int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const
 /* Whole state in the reference's AoS layout, n * 16 (F3) or n * 12 (F4) doubles.  Synchronous. */
 RP_API int rp_batch_set_state(rp_batch *b, const double *aos);
 RP_API int rp_batch_get_state(rp_batch *b, double *aos);
+/* The same for problems [first, first + count): count * 16 (or 12) doubles.  No per-call allocation and only the
+ * requested rows cross PCIe -- what a host that watches ONE problem of the batch calls (printState, onedpath_ip.cpp:997-1006). */
+RP_API int rp_batch_get_state_range(rp_batch *b, size_t first, size_t count, double *aos);
 /* Special-key nudges (onSpecialKey, onedpath_ip.cpp:280-324): var[index] += delta for all problems. */
 RP_API int rp_batch_nudge(rp_batch *b, int var_index, double delta);
 
@@ -140,13 +149,23 @@ RP_API int rp_batch_summary_read(rp_batch *b, rp_reduction *out);
  * positions (33 per segment) and 4 end accelerations, host arrays, synchronous. */
 RP_API int rp_batch_sample(rp_batch *b, double *pos66, double *acc4);
 
+/* The same for problems [first, first + count) only (what onDraw needs for the watched problem). Synchronous. */
+RP_API int rp_batch_sample_range(rp_batch *b, size_t first, size_t count, double *pos66, double *acc4);
+/* The rest of printState for problems [first, first + count): `Surrogate gap` and the `Constraints:` table
+ * (printConstraints, onedpath_ip.cpp:955-995, 1008-1010).  Per problem 1 + 14 m doubles (m = 8 for F3, 4 for F4):
+ * [0] = surrogate gap; then for constraint i at 1 + 14 i: error, deriv[3], second[3][3] row-major, dot = (0,-1,-1).deriv.
+ * Variable order (vel1X, duration0, duration1) as in enum V.  Synchronous. */
+RP_API int rp_batch_constraints_range(rp_batch *b, size_t first, size_t count, double *rows);
+
 /* ---- stream / timing plumbing ---- */
 RP_API int rp_batch_sync(rp_batch *b);
 RP_API int rp_batch_stream(rp_batch *b, void **stream);
 /* HIP events on the batch's own stream: record slot 0..7, elapsed between two recorded slots. */
 RP_API int rp_batch_event_record(rp_batch *b, int slot);
 RP_API int rp_batch_event_elapsed_ms(rp_batch *b, int slot_start, int slot_stop, float *ms);
-/* Device pointer of one SoA field (0..15 / 0..11) for callers that manage their own copies. */
+/* Device pointer of one SoA field (0..15 / 0..11) for callers that manage their own copies.  Asking for an
+ * end-velocity field (vel0X / vel2X) makes the batch assume they may become non-zero (general kernels) until the
+ * next init / set_problems / set_state. */
 RP_API int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr);
 
 #ifdef __cplusplus

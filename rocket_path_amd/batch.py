@@ -92,6 +92,11 @@ class Batch:
         capi.check(self._lib.rp_batch_get_state(self._h, _ptr(a)))
         return a
 
+    def get_state_range(self, first, count):
+        a = np.empty((count, self.state_len), dtype=np.float64)
+        capi.check(self._lib.rp_batch_get_state_range(self._h, first, count, _ptr(a)))
+        return a
+
     def nudge(self, var_index, delta):
         capi.check(self._lib.rp_batch_nudge(self._h, var_index, float(delta)))
 
@@ -126,6 +131,20 @@ class Batch:
         acc = np.empty((self.n, 4), dtype=np.float64)
         capi.check(self._lib.rp_batch_sample(self._h, _ptr(pos), _ptr(acc)))
         return pos, acc
+
+    def sample_range(self, first, count):
+        pos = np.empty((count, 66), dtype=np.float64)
+        acc = np.empty((count, 4), dtype=np.float64)
+        capi.check(self._lib.rp_batch_sample_range(self._h, first, count, _ptr(pos), _ptr(acc)))
+        return pos, acc
+
+    def constraints_range(self, first, count):
+        """printState's `Surrogate gap` and `Constraints:` table: (gap[count], table[count, m, 14]) with columns
+        error, deriv[3], second[9], dot (printConstraints, onedpath_ip.cpp:955-995)."""
+        m = self.num_constraints
+        rows = np.empty((count, 1 + 14 * m), dtype=np.float64)
+        capi.check(self._lib.rp_batch_constraints_range(self._h, first, count, _ptr(rows)))
+        return rows[:, 0].copy(), rows[:, 1:].reshape(count, m, 14).copy()
 
     # ---- plumbing ----
     def sync(self):

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librp_batch.so")
 RP_OK = 0
 RP_ERR_INVALID, RP_ERR_DEVICE, RP_ERR_NOMEM, RP_ERR_UNSUPPORTED, RP_ERR_NO_DEVICE = 1, 2, 3, 4, 5
 VARIANT_F3, VARIANT_F4 = 3, 4
-DTYPE_F64, DTYPE_F32 = 0, 1
+DTYPE_F64, DTYPE_F32, DTYPE_F32_STATE = 0, 1, 2      # 2: fp32 state in HBM, fp64 arithmetic (include/rp_batch.h)
 ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_INFEASIBLE, ST_STALLED = 1, 2, 4, 8, 16
 
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "rp_batch_set_problems_device": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "rp_batch_set_state": (ctypes.c_int, [_vp, _vp]),
     "rp_batch_get_state": (ctypes.c_int, [_vp, _vp]),
+    "rp_batch_get_state_range": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _vp]),
     "rp_batch_nudge": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
     "rp_batch_step": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rp_batch_solve": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
@@ -66,6 +67,8 @@ SIGNATURES = {
     "rp_batch_summary_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "rp_batch_summary_read": (ctypes.c_int, [_vp, ctypes.POINTER(Reduction)]),
     "rp_batch_sample": (ctypes.c_int, [_vp, _vp, _vp]),
+    "rp_batch_sample_range": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
+    "rp_batch_constraints_range": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _vp]),
     "rp_batch_sync": (ctypes.c_int, [_vp]),
     "rp_batch_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "rp_batch_event_record": (ctypes.c_int, [_vp, ctypes.c_int]),

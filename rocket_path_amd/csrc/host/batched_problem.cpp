@@ -5,13 +5,21 @@
 
 #include <cstdio>
 
+// Every handled key of the reference ends in repaint() (onedpath_ip.cpp:256, 261, 266, 271; the special keys 280-324),
+// which posts a GLUT redisplay and so brings onDraw() round (rocket_path.cpp:101-106, 178-182).  Inside the reference
+// tree that very function is called (declared in draw.h:6; not included here because draw.h needs the GL headers);
+// stand-alone hosts register a hook instead.
+#ifdef RP_USE_REFERENCE_PROBLEM_H
+void repaint();
+#endif
+
 namespace {
 inline int numConstraints(int variant) { return variant == RP_VARIANT_F4 ? 4 : 8; }
 inline int stateLen(int variant) { return variant == RP_VARIANT_F4 ? 12 : 16; }
 }  // namespace
 
 BatchedOneDPathIP::BatchedOneDPathIP(size_t n, int variant, int dtype, int device)
-    : batch_(nullptr), n_(n), watched_(0), variant_(variant)
+    : batch_(nullptr), n_(n), watched_(0), variant_(variant), repaintHook_(nullptr)
 {
     check(rp_batch_create(&batch_, variant, dtype, n, device, nullptr), "rp_batch_create");
 }
@@ -26,6 +34,15 @@ bool BatchedOneDPathIP::check(int status, const char *what)
     if (status == RP_OK) return true;
     fprintf(stderr, "BatchedOneDPathIP: %s failed: %s (%s)\n", what, rp_status_string(status), rp_last_error());
     return false;
+}
+
+void BatchedOneDPathIP::requestRepaint()
+{
+#ifdef RP_USE_REFERENCE_PROBLEM_H
+    repaint();
+#else
+    if (repaintHook_) repaintHook_();
+#endif
 }
 
 void BatchedOneDPathIP::init()
@@ -55,15 +72,21 @@ void BatchedOneDPathIP::onKey(unsigned char key)
     switch (key) {
     case ' ':
         check(rp_batch_move_toward_feasibility(batch_), "rp_batch_move_toward_feasibility");
+        requestRepaint();
         break;
     case 'i':
         check(rp_batch_init_default(batch_), "rp_batch_init_default");
+        requestRepaint();
         break;
     case 'j':
-        if (variant_ == RP_VARIANT_F3) check(rp_batch_init_stuck(batch_), "rp_batch_init_stuck");
+        if (variant_ == RP_VARIANT_F3) {
+            check(rp_batch_init_stuck(batch_), "rp_batch_init_stuck");
+            requestRepaint();
+        }
         break;
     case 'n':
         step(1);
+        requestRepaint();
         break;
     case 's':
         printState();
@@ -84,16 +107,18 @@ void BatchedOneDPathIP::onSpecialKey(int key)
     case RP_KEY_RIGHT:     check(rp_batch_nudge(batch_, 0, 1.0), "nudge"); break;
     case RP_KEY_UP:        check(rp_batch_nudge(batch_, pos1, 10.0), "nudge"); break;
     case RP_KEY_DOWN:      check(rp_batch_nudge(batch_, pos1, -10.0), "nudge"); break;
+    default: return;      // the reference repaints only after a key it handles (onedpath_ip.cpp:280-324)
     }
+    requestRepaint();
 }
 
 void BatchedOneDPathIP::onDraw()
 {
     if (!batch_) return;
-    std::vector<double> pos(n_ * 66), acc(n_ * 4);
-    if (!check(rp_batch_sample(batch_, pos.data(), acc.data()), "rp_batch_sample")) return;
-    plotPos_.assign(pos.begin() + watched_ * 66, pos.begin() + (watched_ + 1) * 66);
-    plotAcc_.assign(acc.begin() + watched_ * 4, acc.begin() + (watched_ + 1) * 4);
+    // the watched problem only: 70 doubles cross PCIe, whatever the batch size
+    plotPos_.resize(66);
+    plotAcc_.resize(4);
+    check(rp_batch_sample_range(batch_, watched_, 1, plotPos_.data(), plotAcc_.data()), "rp_batch_sample_range");
 }
 
 void BatchedOneDPathIP::setProblems(const double *pos0, const double *pos1, const double *pos2)
@@ -133,14 +158,17 @@ bool BatchedOneDPathIP::reduce(rp_reduction &out)
     return batch_ && check(rp_batch_reduce(batch_, &out), "rp_batch_reduce");
 }
 
-// printState of the watched problem in the reference's format (onedpath_ip.cpp:997-1010),
-// followed by the batch summary that replaces the reference's per-step dump.
+// printState of the watched problem, line for line the reference's (onedpath_ip.cpp:997-1010 with printConstraints
+// 955-995; F4: onedpath2_ip.cpp:885-898), followed by the batch summary that replaces the reference's per-step dump
+// and a full-precision line for tools.  Only the watched problem's rows cross PCIe.
 void BatchedOneDPathIP::printState()
 {
-    std::vector<double> aos;
-    if (!readState(aos)) return;
+    if (!batch_) return;
     const int m = numConstraints(variant_), M = stateLen(variant_);
-    const double *v = aos.data() + watched_ * M;
+    std::vector<double> row(M), table(1 + 14 * m);
+    if (!check(rp_batch_get_state_range(batch_, watched_, 1, row.data()), "rp_batch_get_state_range")) return;
+    if (!check(rp_batch_constraints_range(batch_, watched_, 1, table.data()), "rp_batch_constraints_range")) return;
+    const double *v = row.data();
     const double *c = v + 3 + m;   // pos0, vel0, pos1, pos2, vel2
     printf("\nNode 0: pos=%g vel=%g\n", c[0], c[1]);
     printf("Node 1: pos=%g vel=%g\n", c[2], v[0]);
@@ -150,6 +178,27 @@ void BatchedOneDPathIP::printState()
     printf("Constraint Multipliers:");
     for (int i = 0; i < m; ++i) printf(" %g", v[3 + i]);
     printf("\n");
+    printf("Surrogate gap: %g\n", table[0]);
+    printf("Constraints:\n");
+    if (variant_ == RP_VARIANT_F4) {      // F4's table has a header naming the columns (onedpath2_ip.cpp:848-863)
+        static const char *const name[3] = {"v1", "t0", "t1"};
+        printf("[%s %s %s] [", name[0], name[1], name[2]);
+        for (int i = 0; i < 3; ++i) printf("%s[%s/%s %s/%s %s/%s]", (i > 0) ? " " : "", name[i], name[0], name[i], name[1], name[i], name[2]);
+        printf("]\n");
+    }
+    for (int i = 0; i < m; ++i) {
+        const double *t = table.data() + 1 + 14 * i;      // error, deriv[3], second[3][3], dot
+        printf("%c%u:", (t[0] > 0) ? '*' : ' ', (unsigned)i);
+        printf(" error=%g derivs=[", t[0]);
+        for (int j = 0; j < 3; ++j) printf("%s%g", (j > 0) ? " " : "", t[1 + j]);
+        printf("] second=[");
+        for (int j = 0; j < 3; ++j) {
+            printf("%s[", (j > 0) ? " " : "");
+            for (int k = 0; k < 3; ++k) printf("%s%g", (k > 0) ? " " : "", t[4 + 3 * j + k]);
+            printf("]");
+        }
+        printf("] dot=%g\n", t[13]);
+    }
     rp_reduction r;
     if (reduce(r)) {
         printf("Batch: %zu problems, max surrogate gap: %g, max residual^2: %g, converged: %.0f, steps: %.0f\n", n_, r.max_gap,

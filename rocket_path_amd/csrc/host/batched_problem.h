@@ -24,7 +24,8 @@ struct BatchedOneDPathIP : public Problem {
     void onActivate() override;            // help text (onedpath_ip.cpp:235-248)
     void onKey(unsigned char key) override;    // onedpath_ip.cpp:250-278
     void onSpecialKey(int key) override;       // onedpath_ip.cpp:280-324
-    void onDraw() override;                // fills plotPositions()/plotAccelerations() for the watched problem
+    void onDraw() override;                // fills plotPositions()/plotAccelerations() for the watched problem (70 doubles read back);
+                                           // the GL calls that draw them (onedpath_ip.cpp:336-358, 1015-1148) are the shell's to add
     void onMouseMove(int, int) override {}
     void onMouseDown() override {}
     void onMouseUp() override {}
@@ -42,12 +43,17 @@ struct BatchedOneDPathIP : public Problem {
     const std::vector<double> &plotPositions() const { return plotPos_; }
     const std::vector<double> &plotAccelerations() const { return plotAcc_; }
     rp_batch *handle() { return batch_; }
+    // Stand-alone hosts: called after every handled key, where the reference calls repaint() (draw.h:6).  Built inside the
+    // reference tree (RP_USE_REFERENCE_PROBLEM_H) the class calls the shell's own repaint() and this hook is unused.
+    void setRepaintHook(void (*hook)()) { repaintHook_ = hook; }
 
 private:
     void printState();
+    void requestRepaint();
     bool check(int status, const char *what);
     rp_batch *batch_;
     size_t n_, watched_;
     int variant_;
     std::vector<double> plotPos_, plotAcc_;
+    void (*repaintHook_)();
 };

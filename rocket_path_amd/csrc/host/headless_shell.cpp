@@ -5,7 +5,12 @@
 // to the current problem, F-keys switch problems.  The F3 and F4 slots hold the batched GPU
 // problems; F1/F2 (fixptpath, onedpath) are out of scope and left empty.
 //
-//   rp_headless [--n N] [--seed S] [--f4] [--f32] [--gpus G] [--keys "i n n s"] [--solve]
+//   rp_headless [--n N] [--seed S] [--f4] [--f32] [--gpus G] [--watch I] [--keys "i n n s"] [--solve]
+//
+// Redisplay works as under GLUT: a handled key makes the problem call repaint() (here: the hook below marks the
+// window dirty, as glutPostRedisplay does, rocket_path.cpp:178-182), and the shell then calls onDraw() on the current
+// problem once (rocket_path.cpp:101-106).  The number of redraws is reported on stderr at exit; the token `p` prints
+// what the last onDraw() fetched for the watched problem (--watch I, default 0).
 //
 // --gpus G (G >= 1) puts a ShardedOneDPathIP (G devices, one process, RCCL summary) in the F3 slot.
 //
@@ -34,6 +39,9 @@ uint64_t mix(uint64_t z)
 }
 double u01(uint64_t seed, uint64_t ctr) { return (double)(mix(seed + ctr) >> 11) * (1.0 / 9007199254740992.0); }
 
+bool g_dirty = false;
+void postRedisplay() { g_dirty = true; }
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -42,6 +50,8 @@ int main(int argc, char **argv)
     uint64_t seed = 0;
     bool haveSeed = false, solve = false, f32 = false, startF4 = false;
     int gpus = 0;
+    size_t watch = 0;
+    unsigned redraws = 0;
     std::string keys = "s";
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--n") && i + 1 < argc) n = (size_t)strtoull(argv[++i], nullptr, 10);
@@ -51,6 +61,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--f32")) f32 = true;
         else if (!strcmp(argv[i], "--f4")) startF4 = true;
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--watch") && i + 1 < argc) watch = (size_t)strtoull(argv[++i], nullptr, 10);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     if (n == 0) { fprintf(stderr, "--n must be positive\n"); return 2; }
@@ -84,6 +95,10 @@ int main(int argc, char **argv)
     BatchedOneDPathIP problem3(n, RP_VARIANT_F3, f32 ? RP_DTYPE_F32 : RP_DTYPE_F64);
     BatchedOneDPathIP problem4(n, RP_VARIANT_F4, f32 ? RP_DTYPE_F32 : RP_DTYPE_F64);
     if (!problem3.ok() || !problem4.ok()) return 1;
+    problem3.setRepaintHook(postRedisplay);
+    problem4.setRepaintHook(postRedisplay);
+    problem3.watch(watch);
+    problem4.watch(watch);
     Problem *problems[] = {nullptr, nullptr, &problem3, &problem4};   // F1, F2 out of scope
     Problem *cur = startF4 ? problems[3] : problems[2];               // F3 is the reference's default (rocket_path.cpp:46)
 
@@ -106,7 +121,14 @@ int main(int argc, char **argv)
     while (in >> tok) {
         if (tok == "F3" || tok == "F4") {
             Problem *p = problems[tok == "F3" ? 2 : 3];
-            if (p != cur) { cur = p; cur->onActivate(); }
+            if (p != cur) { cur = p; cur->onActivate(); postRedisplay(); }      // rocket_path.cpp:151-156
+        } else if (tok == "p") {
+            BatchedOneDPathIP *b = static_cast<BatchedOneDPathIP *>(cur);
+            printf("Plot:");
+            for (double x : b->plotPositions()) printf(" %.17g", x);
+            printf(" |");
+            for (double x : b->plotAccelerations()) printf(" %.17g", x);
+            printf("\n");
         } else if (tok == "SPACE") cur->onKey(' ');
         else if (tok == "HOME") cur->onSpecialKey(RP_KEY_HOME);
         else if (tok == "END") cur->onSpecialKey(RP_KEY_END);
@@ -119,6 +141,12 @@ int main(int argc, char **argv)
         else if (tok.size() > 1 && tok[0] == 'n') static_cast<BatchedOneDPathIP *>(cur)->step(atoi(tok.c_str() + 1));
         else if (tok.size() == 1) cur->onKey((unsigned char)tok[0]);
         else { fprintf(stderr, "unknown key token %s\n", tok.c_str()); return 2; }
+        if (g_dirty) {      // the display callback
+            g_dirty = false;
+            cur->onDraw();
+            ++redraws;
+        }
     }
+    fprintf(stderr, "redraws: %u\n", redraws);
     return 0;
 }

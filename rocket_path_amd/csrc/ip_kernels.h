@@ -16,7 +16,7 @@ struct BatchView {
     size_t stride;         // elements between consecutive fields
     size_t n;              // problems
     int variant;           // 3 or 4
-    int dtype;             // 0 = f64, 1 = f32
+    int dtype;             // 0 = f64, 1 = f32, 2 = f32 state with f64 arithmetic (RP_DTYPE_* of rp_batch.h)
     bool zero_end_vel;     // vel0X == vel2X == 0 for every problem (true after every init the reference has; see Prob in ip_core.h)
     int32_t *iters;        // gated Newton steps taken per problem
     uint32_t *status;      // RP_ST_* bits per problem
@@ -31,6 +31,7 @@ struct HostParams {
 };
 
 inline int state_len(int variant) { return variant == 4 ? 12 : 16; }
+inline size_t storage_size(int dtype) { return dtype == 0 ? 8 : 4; }      // bytes per state element in HBM
 inline int num_constraints(int variant) { return variant == 4 ? 4 : 8; }
 
 // k ungated Newton steps per problem, one launch.
@@ -57,5 +58,10 @@ hipError_t launch_order(const BatchView &b, hipStream_t stream);
 // the rows either side of the hot path
 hipError_t launch_move_toward_feasibility(const BatchView &b, const HostParams &hp, hipStream_t stream);
 hipError_t launch_sample(const BatchView &b, double *d_pos66, double *d_acc4, hipStream_t stream);
+
+// the same on a window [first, first + count) of the batch, plus printState's constraint table (1 + 14 m doubles per problem)
+hipError_t launch_soa_to_aos_range(const BatchView &b, size_t first, size_t count, double *d_aos, hipStream_t stream);
+hipError_t launch_sample_range(const BatchView &b, size_t first, size_t count, double *d_pos66, double *d_acc4, hipStream_t stream);
+hipError_t launch_constraint_table(const BatchView &b, const HostParams &hp, size_t first, size_t count, double *d_rows, hipStream_t stream);
 
 }  // namespace rp

@@ -73,7 +73,10 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 // The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
 // STALL: compile the stall detector in (two more live registers); the tiled solve instantiates both
 // forms and picks by rp_params.stall_window, so the default (off) pays nothing for it.
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>>
+// S = storage type of the batch.  When it differs from the compute type T (fp32 state, fp64 arithmetic) the state is
+// rounded to S after every step, so that a step is a function "S state -> S state" whatever the launch shape:
+// step(k) stays bit-identical to k x step(1).
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open)
@@ -101,6 +104,16 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
             }
         }
         newton_step<T, VARIANT, P>(pr, kp, gap, v, t0, t1, lam, e);
+        if constexpr (sizeof(S) != sizeof(T)) {
+            v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
+#pragma unroll
+            for (int c = 0; c < CMap<VARIANT>::NC; ++c) lam[c] = (T)(S)lam[c];
+            Acc<T> er;                       // the carried evaluation belongs to the unrounded point
+            accel_values(pr, v, t0, t1, er);
+            e.r0 = er.r0; e.r1 = er.r1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e.a[j] = er.a[j];
+        }
         ++it;
         ++steps_here;
     }
@@ -117,9 +130,9 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     }
 }
 
-template <typename T, int VARIANT, bool GATED, bool ZV>
+template <typename S, typename T, int VARIANT, bool GATED, bool ZV>
 __global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
-k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
+k_newton(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
          int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters)
 {
     constexpr int NC = CMap<VARIANT>::NC;
@@ -139,32 +152,32 @@ k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
     bool still_open = false;
 
     if (active) {
-        T *f = base + i;
-        T v = f[0 * stride], t0 = f[1 * stride], t1 = f[2 * stride];
+        S *f = base + i;
+        T v = (T)f[0 * stride], t0 = (T)f[1 * stride], t1 = (T)f[2 * stride];
         T lam[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) lam[c] = f[(3 + c) * stride];
+        for (int c = 0; c < NC; ++c) lam[c] = (T)f[(3 + c) * stride];
         Prob<T, ZV> pr;
         {
-            const T p0 = f[(CB + 0) * stride], p1 = f[(CB + 2) * stride], p2 = f[(CB + 3) * stride];
+            const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
             if constexpr (!ZV) {
-                pr.v0 = f[(CB + 1) * stride];
-                pr.v2 = f[(CB + 4) * stride];
+                pr.v0 = (T)f[(CB + 1) * stride];
+                pr.v2 = (T)f[(CB + 4) * stride];
             }
             pr.dx0 = p1 - p0;
             pr.dx1 = p2 - p1;
         }
-        run_lane<T, VARIANT, GATED, GATED, Prob<T, ZV>>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, GATED, GATED, Prob<T, ZV>, S>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
         if (GATED) {
             iters[i] = it;
             status[i] = st;
         }
         if (steps_here > 0) {
-            f[0 * stride] = v;
-            f[1 * stride] = t0;
-            f[2 * stride] = t1;
+            f[0 * stride] = (S)v;
+            f[1 * stride] = (S)t0;
+            f[2 * stride] = (S)t1;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = lam[c];
+            for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = (S)lam[c];
         }
     }
 
@@ -189,16 +202,16 @@ k_newton(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
 // next state streams in under the arithmetic of the current one.
 template <typename T, int NF> struct LaneState { T f[NF]; };
 
-template <typename T, int VARIANT, bool ZV>
+template <typename S, typename T, int VARIANT, bool ZV>
 __global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
-k_newton_stream(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
+k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
     constexpr int NF = CB + 5;
     const size_t step = (size_t)gridDim.x * kBlock;
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    LaneState<T, NF> cur, nxt;
+    LaneState<S, NF> cur, nxt;      // the prefetched state waits in the storage type
     if (i >= n) return;
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -213,27 +226,27 @@ k_newton_stream(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
 #pragma unroll
         for (int f = 0; f < NF; ++f)
             if (!(ZV && (f == CB + 1 || f == CB + 4))) nxt.f[f] = base[(size_t)f * stride + src];
-        T v = cur.f[0], t0 = cur.f[1], t1 = cur.f[2];
+        T v = (T)cur.f[0], t0 = (T)cur.f[1], t1 = (T)cur.f[2];
         T lam[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) lam[c] = cur.f[3 + c];
+        for (int c = 0; c < NC; ++c) lam[c] = (T)cur.f[3 + c];
         Prob<T, ZV> pr;
         if constexpr (!ZV) {
-            pr.v0 = cur.f[CB + 1];
-            pr.v2 = cur.f[CB + 4];
+            pr.v0 = (T)cur.f[CB + 1];
+            pr.v2 = (T)cur.f[CB + 4];
         }
-        pr.dx0 = cur.f[CB + 2] - cur.f[CB + 0];
-        pr.dx1 = cur.f[CB + 3] - cur.f[CB + 2];
+        pr.dx0 = (T)cur.f[CB + 2] - (T)cur.f[CB + 0];
+        pr.dx1 = (T)cur.f[CB + 3] - (T)cur.f[CB + 2];
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
-        T *f = base + i;
-        f[0 * stride] = v;
-        f[1 * stride] = t0;
-        f[2 * stride] = t1;
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        S *f = base + i;
+        f[0 * stride] = (S)v;
+        f[1 * stride] = (S)t0;
+        f[2 * stride] = (S)t1;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = lam[c];
+        for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = (S)lam[c];
         if (!have_next) break;
         cur = nxt;
         i = inext;
@@ -304,15 +317,15 @@ k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__r
 // staging (for k >= 3 the arithmetic dominates, and this is the form that fits three waves per SIMD).
 // Only the default instantiations (zero end velocities, stall detector off) fit 168 VGPRs without spilling; the
 // others are held to two waves per SIMD instead (any scratch makes the launch time erratic).
-template <typename T, int VARIANT, bool GATED, bool STALL, bool ZV>
+template <typename S, typename T, int VARIANT, bool GATED, bool STALL, bool ZV>
 __global__ void __launch_bounds__(kBlock, (STALL || !ZV) ? 2 : RP_TILED_WAVES)
-k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
+k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
               const uint16_t *__restrict__ order)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
-    __shared__ T sm[CB][kTile];            // the mutable fields only; the five constants are read once per problem
+    __shared__ S sm[CB][kTile];            // the mutable fields only; the five constants are read once per problem
     __shared__ int32_t s_it[GATED ? kTile : 1];
     __shared__ uint32_t s_st[GATED ? kTile : 1];
 
@@ -344,17 +357,17 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
         bool live = j >= 0;
         if (GATED && live) live = (s_st[j] & (RP_ST_CONVERGED | RP_ST_MAXITER | RP_ST_STALLED)) == 0;
         if (live) {
-            T v = sm[0][j], t0 = sm[1][j], t1 = sm[2][j];
+            T v = (T)sm[0][j], t0 = (T)sm[1][j], t1 = (T)sm[2][j];
             T lam[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) lam[c] = sm[3 + c][j];
+            for (int c = 0; c < NC; ++c) lam[c] = (T)sm[3 + c][j];
             Prob<T, ZV> pr;     // constants: a gather inside the tile's 4 KiB window of each field, once per problem
             {
-                const T *g = base + first + j;
-                const T q0 = g[(size_t)(CB + 0) * stride], q1 = g[(size_t)(CB + 2) * stride], q2 = g[(size_t)(CB + 3) * stride];
+                const S *g = base + first + j;
+                const T q0 = (T)g[(size_t)(CB + 0) * stride], q1 = (T)g[(size_t)(CB + 2) * stride], q2 = (T)g[(size_t)(CB + 3) * stride];
                 if constexpr (!ZV) {
-                    pr.v0 = g[(size_t)(CB + 1) * stride];
-                    pr.v2 = g[(size_t)(CB + 4) * stride];
+                    pr.v0 = (T)g[(size_t)(CB + 1) * stride];
+                    pr.v2 = (T)g[(size_t)(CB + 4) * stride];
                 }
                 pr.dx0 = q1 - q0;
                 pr.dx1 = q2 - q1;
@@ -362,13 +375,13 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
             int it = GATED ? s_it[j] : 0;
             uint32_t st = GATED ? s_st[j] : 0u;
             bool still_open = false;
-            run_lane<T, VARIANT, GATED, STALL, Prob<T, ZV>>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+            run_lane<T, VARIANT, GATED, STALL, Prob<T, ZV>, S>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
             open_any = open_any || still_open;
-            sm[0][j] = v;
-            sm[1][j] = t0;
-            sm[2][j] = t1;
+            sm[0][j] = (S)v;
+            sm[1][j] = (S)t0;
+            sm[2][j] = (S)t1;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) sm[3 + c][j] = lam[c];
+            for (int c = 0; c < NC; ++c) sm[3 + c][j] = (S)lam[c];
             if (GATED) { s_it[j] = it; s_st[j] = st; }
         }
     }
@@ -395,9 +408,9 @@ k_solve_tiled(T *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
 // Block partials go to d_partials[4 * blockIdx]; k_reduce_final folds them (max, max, sum, sum).
 __device__ __forceinline__ double nan_max(double a, double b) { return (a > b || a != a) ? a : b; }
 
-template <typename T, int VARIANT>
+template <typename S, typename T, int VARIANT>
 __global__ void __launch_bounds__(kBlock)
-k_reduce_partial(const T *__restrict__ base, size_t stride, size_t n, KParams<T> kp,
+k_reduce_partial(const S *__restrict__ base, size_t stride, size_t n, KParams<T> kp,
                  const uint32_t *__restrict__ status, double *__restrict__ partials)
 {
     constexpr int NC = CMap<VARIANT>::NC;
@@ -405,19 +418,19 @@ k_reduce_partial(const T *__restrict__ base, size_t stride, size_t n, KParams<T>
     double mr = 0.0, mg = -1.7976931348623157e308, nc = 0.0;
     bool any = false;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-        const T *f = base + i;
+        const S *f = base + i;
         T lam[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) lam[c] = f[(3 + c) * stride];
+        for (int c = 0; c < NC; ++c) lam[c] = (T)f[(3 + c) * stride];
         Prob<T> pr;
-        const T p0 = f[(CB + 0) * stride], p1 = f[(CB + 2) * stride], p2 = f[(CB + 3) * stride];
-        pr.v0 = f[(CB + 1) * stride];
-        pr.v2 = f[(CB + 4) * stride];
+        const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
+        pr.v0 = (T)f[(CB + 1) * stride];
+        pr.v2 = (T)f[(CB + 4) * stride];
         pr.dx0 = p1 - p0;
         pr.dx1 = p2 - p1;
-        const T v = f[0];
+        const T v = (T)f[0];
         Acc<T> e;
-        accel_values(pr, v, f[1 * stride], f[2 * stride], e);
+        accel_values(pr, v, (T)f[1 * stride], (T)f[2 * stride], e);
         accel_grads(pr, v, e);
         const T gap = duality_gap<T, VARIANT>(e, lam, kp.limit);
         const T rn = residual_norm<T, VARIANT, false>(e, lam, lam, T(0), gap * kp.inv_mu_den, kp.limit);
@@ -567,30 +580,27 @@ __global__ void __launch_bounds__(64) k_zero_counter(unsigned long long *c) { c[
 
 // ---------------------------------------------------------------------------------------
 // moveTowardFeasibility (onedpath_ip.cpp:648-721 / onedpath2_ip.cpp:536-609), one lane per problem.
-template <typename T, int VARIANT>
+template <typename S, typename T, int VARIANT>
 __global__ void __launch_bounds__(kBlock)
-k_move_toward_feasibility(T *__restrict__ base, size_t stride, size_t n, KParams<T> kp)
+k_move_toward_feasibility(S *__restrict__ base, size_t stride, size_t n, KParams<T> kp)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    T *f = base + i;
+    S *f = base + i;
     Prob<T> pr;
-    const T p0 = f[(CB + 0) * stride], p1 = f[(CB + 2) * stride], p2 = f[(CB + 3) * stride];
-    pr.v0 = f[(CB + 1) * stride];
-    pr.v2 = f[(CB + 4) * stride];
+    const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
+    pr.v0 = (T)f[(CB + 1) * stride];
+    pr.v2 = (T)f[(CB + 4) * stride];
     pr.dx0 = p1 - p0;
     pr.dx1 = p2 - p1;
-    T v = f[0], t0 = f[1 * stride], t1 = f[2 * stride];
-    Acc<T> e;
-    accel_values(pr, v, t0, t1, e);
-    accel_grads(pr, v, e);
+    T v = (T)f[0], t0 = (T)f[1 * stride], t1 = (T)f[2 * stride];
     T dxv, dx0, dx1;
-    if (feasibility_move<T, VARIANT>(e, kp.limit, dxv, dx0, dx1)) {
-        f[0] = v + dxv;
-        f[1 * stride] = t0 + dx0;
-        f[2 * stride] = t1 + dx1;
+    if (feasibility_move<T, VARIANT>(pr.dx0, pr.dx1, pr.v0, pr.v2, v, t0, t1, kp.limit, dxv, dx0, dx1)) {
+        f[0] = (S)(v + dxv);
+        f[1 * stride] = (S)(t0 + dx0);
+        f[2 * stride] = (S)(t1 + dx1);
     }
 }
 
@@ -633,20 +643,83 @@ k_sample(const T *__restrict__ base, size_t stride, size_t n, double *__restrict
     }
 }
 
+// printState's per-problem part for a (small) range of problems: the surrogate gap and, per constraint, what
+// printConstraints shows (onedpath_ip.cpp:955-995, 1008-1010): error, gradient, the 3x3 second-derivative
+// matrix and dot = (0,-1,-1).gradient.  Row layout per problem, in doubles:
+//     [0] gap, then for constraint i at 1 + 14 i: error, deriv[3], second[3][3] (row-major), dot.
+// Same device functions as the step (accel_values / accel_grads / accel_hess, c_value, c_grad), so what is
+// printed is what the kernels step on.
+template <typename S, typename T, int VARIANT>
+__global__ void __launch_bounds__(kBlock)
+k_constraint_table(const S *__restrict__ base, size_t stride, size_t first, size_t count, KParams<T> kp, double *__restrict__ out)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    constexpr int CB = 3 + NC;
+    constexpr int ROW = 1 + 14 * NC;
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= count) return;
+    const S *f = base + first + j;
+    Prob<T> pr;
+    const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
+    pr.v0 = (T)f[(CB + 1) * stride];
+    pr.v2 = (T)f[(CB + 4) * stride];
+    pr.dx0 = p1 - p0;
+    pr.dx1 = p2 - p1;
+    const T v = (T)f[0];
+    T lam[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) lam[c] = (T)f[(3 + c) * stride];
+    Acc<T> e;
+    accel_values(pr, v, (T)f[1 * stride], (T)f[2 * stride], e);
+    accel_grads(pr, v, e);
+    T htt[4], htv[4];
+    accel_hess(pr, v, e, htt, htv);
+    double *o = out + j * ROW;
+    o[0] = (double)duality_gap<T, VARIANT>(e, lam, kp.limit);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        T gv, gt;
+        c_grad<T, VARIANT>(i, e, gv, gt);
+        const int seg = c_segment<VARIANT>(i);
+        T Htt, Htv;      // second derivatives of c_i: (t,t) and (t,v) = (v,t); everything else 0
+        if constexpr (VARIANT == 3) {
+            const int a = i >> 1;
+            Htt = (i & 1) ? htt[a] : -htt[a];
+            Htv = (i & 1) ? htv[a] : -htv[a];
+        } else {      // (a^2 - L^2)/2; the (vel1,vel1) entry is never written by the reference (onedpath2_ip.cpp:446-448)
+            Htt = fma_(e.gt[i], e.gt[i], e.a[i] * htt[i]);
+            Htv = fma_(e.gt[i], acc_gv(e, i), e.a[i] * htv[i]);
+        }
+        double *r = o + 1 + 14 * i;
+        r[0] = (double)c_value<T, VARIANT>(i, e, kp.limit);
+        r[1] = (double)gv;
+        r[2] = seg == 0 ? (double)gt : 0.0;
+        r[3] = seg == 0 ? 0.0 : (double)gt;
+        for (int q = 0; q < 9; ++q) r[4 + q] = 0.0;
+        const int t = 1 + seg;      // index of this constraint's duration among (vel1, t0, t1)
+        r[4 + 3 * t + t] = (double)Htt;
+        r[4 + 3 * 0 + t] = (double)Htv;
+        r[4 + 3 * t + 0] = (double)Htv;
+        r[13] = -(r[2] + r[3]);     // obj = (0, -1, -1)
+    }
+}
+
 inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-// dispatch on (dtype, variant)
-#define RP_DISPATCH(b, ...)                                               \
+// dispatch on (dtype, variant): S = storage type in HBM, T = arithmetic type in registers
+//   RP_DTYPE_F64        double / double
+//   RP_DTYPE_F32        float  / float
+//   RP_DTYPE_F32_STATE  float  / double   (fp32 state and traffic, fp64 arithmetic)
+#define RP_DISPATCH_V(b, ...)                                             \
     do {                                                                  \
-        if ((b).dtype == 0) {                                             \
-            using T = double;                                             \
-            if ((b).variant == 3) { constexpr int V = 3; __VA_ARGS__; }   \
-            else                  { constexpr int V = 4; __VA_ARGS__; }   \
-        } else {                                                          \
-            using T = float;                                              \
-            if ((b).variant == 3) { constexpr int V = 3; __VA_ARGS__; }   \
-            else                  { constexpr int V = 4; __VA_ARGS__; }   \
-        }                                                                 \
+        if ((b).variant == 3) { constexpr int V = 3; __VA_ARGS__; }       \
+        else                  { constexpr int V = 4; __VA_ARGS__; }       \
+    } while (0)
+#define RP_DISPATCH(b, ...)                                                                              \
+    do {                                                                                                 \
+        if ((b).dtype == 0)      { using S [[maybe_unused]] = double; using T [[maybe_unused]] = double; RP_DISPATCH_V(b, __VA_ARGS__); } \
+        else if ((b).dtype == 1) { using S [[maybe_unused]] = float;  using T [[maybe_unused]] = float;  RP_DISPATCH_V(b, __VA_ARGS__); } \
+        else                     { using S [[maybe_unused]] = float;  using T [[maybe_unused]] = double; RP_DISPATCH_V(b, __VA_ARGS__); } \
     } while (0)
 
 }  // namespace
@@ -669,8 +742,8 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override: forces the streaming kernel
     if (k >= 3 && !grid_env && b.n >= (size_t)kTile * 512) {
         const unsigned tiles = (unsigned)((b.n + kTile - 1) / kTile);
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, false, false, Z>), dim3(tiles), dim3(kBlock), 0, stream,
-                                             (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), T(0), 0,
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, false, false, Z>), dim3(tiles), dim3(kBlock), 0, stream,
+                                             (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), T(0), 0,
                                              (int32_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr,
                                              (const uint16_t *)b.order));
         return hipGetLastError();
@@ -678,8 +751,8 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     const unsigned cap = grid_env ? (unsigned)atoi(grid_env) : 512u;
     unsigned grid = grid_for(b.n);
     if (grid > cap) grid = cap;
-    RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton_stream<T, V, Z>), dim3(grid), dim3(kBlock), 0, stream,
-                                         (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
+    RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton_stream<S, T, V, Z>), dim3(grid), dim3(kBlock), 0, stream,
+                                         (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
     return hipGetLastError();
 }
 
@@ -691,19 +764,19 @@ hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double g
     // 512 problems): small batches take the plain one-problem-per-lane kernel.
     static const bool no_tiled = getenv("RP_NO_TILED") != nullptr;     // A/B switch for tuning
     if (no_tiled || b.n < (size_t)kTile * 512) {
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                             (T *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                             (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
                                              (T)gap_tol, max_iter, b.iters, b.status, b.counters));
         return hipGetLastError();
     }
     const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
     if (hp.stall_window > 0)
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, true, true, Z>), dim3(grid), dim3(kBlock), 0, stream,
-                                             (T *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, true, true, Z>), dim3(grid), dim3(kBlock), 0, stream,
+                                             (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
                                              (T)gap_tol, max_iter, b.iters, b.status, b.counters, (const uint16_t *)b.order));
     else
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<T, V, true, false, Z>), dim3(grid), dim3(kBlock), 0, stream,
-                                             (T *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, true, false, Z>), dim3(grid), dim3(kBlock), 0, stream,
+                                             (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
                                              (T)gap_tol, max_iter, b.iters, b.status, b.counters, (const uint16_t *)b.order));
     return hipGetLastError();
 }
@@ -712,8 +785,8 @@ hipError_t launch_order(const BatchView &b, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_order_tiles<T, V>), dim3(grid), dim3(kBlock), 0, stream,
-                                       (const T *)b.base, b.stride, b.n, b.order));
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_order_tiles<S, V>), dim3(grid), dim3(kBlock), 0, stream,
+                                       (const S *)b.base, b.stride, b.n, b.order));
     return hipGetLastError();
 }
 
@@ -721,8 +794,8 @@ hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double 
 {
     if (b.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(kShards), 0, stream, b.counters);
-    RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                         (T *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
+    RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                         (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
                                          b.iters, b.status, b.counters));
     return hipGetLastError();
 }
@@ -732,8 +805,8 @@ hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_s
 {
     unsigned blocks = grid_for(b.n);
     if (blocks > 1024) blocks = 1024;
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_reduce_partial<T, V>), dim3(blocks), dim3(kBlock), 0, stream,
-                                       (const T *)b.base, b.stride, b.n, make_kparams<T>(hp, V), b.status, d_partials));
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_reduce_partial<S, T, V>), dim3(blocks), dim3(kBlock), 0, stream,
+                                       (const S *)b.base, b.stride, b.n, make_kparams<T>(hp, V), b.status, d_partials));
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(64), 0, stream, d_partials, (int)blocks, b.counters, host_steps, d_out4);
     return hipGetLastError();
 }
@@ -741,7 +814,7 @@ hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_s
 hipError_t launch_aos_to_soa(const BatchView &b, const double *d_aos, hipStream_t stream)
 {
     const dim3 g(grid_for(b.n)), t(kBlock);
-    if (b.dtype == 0) {
+    if (b.dtype == 0) {      // storage type only: dtype 1 and 2 both keep floats
         if (b.variant == 3) hipLaunchKernelGGL((k_aos_to_soa<double, 16>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n);
         else                hipLaunchKernelGGL((k_aos_to_soa<double, 12>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n);
     } else {
@@ -767,8 +840,8 @@ hipError_t launch_soa_to_aos(const BatchView &b, double *d_aos, hipStream_t stre
 hipError_t launch_init_feasible(const BatchView &b, const HostParams &hp, const double *d_pos0, const double *d_pos1,
                                 const double *d_pos2, hipStream_t stream)
 {
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_init_feasible<T, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                       (T *)b.base, b.stride, b.n, hp.accel_limit, d_pos0, d_pos1, d_pos2));
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_init_feasible<S, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                       (S *)b.base, b.stride, b.n, hp.accel_limit, d_pos0, d_pos1, d_pos2));
     return hipGetLastError();
 }
 
@@ -797,16 +870,45 @@ hipError_t launch_clear_progress(const BatchView &b, hipStream_t stream)
 
 hipError_t launch_move_toward_feasibility(const BatchView &b, const HostParams &hp, hipStream_t stream)
 {
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_move_toward_feasibility<T, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                       (T *)b.base, b.stride, b.n, make_kparams<T>(hp, V)));
+    // Always in double, whatever the batch's arithmetic type: the move squares the conditioning of the constraint
+    // gradients (Gram matrix), which single precision cannot carry (measured: 10 % of fp32 moves off by > 6e-3), and
+    // it is a one-off between solves, not the hot path.  An fp32 state gets the fp64 move rounded to fp32.
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_move_toward_feasibility<S, double, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                       (S *)b.base, b.stride, b.n, make_kparams<double>(hp, V)));
     return hipGetLastError();
 }
 
 hipError_t launch_sample(const BatchView &b, double *d_pos66, double *d_acc4, hipStream_t stream)
 {
     const size_t total = b.n * 70;
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_sample<T, V>), dim3(grid_for(total)), dim3(kBlock), 0, stream,
-                                       (const T *)b.base, b.stride, b.n, d_pos66, d_acc4));
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_sample<S, V>), dim3(grid_for(total)), dim3(kBlock), 0, stream,
+                                       (const S *)b.base, b.stride, b.n, d_pos66, d_acc4));
+    return hipGetLastError();
+}
+
+// ---- ranges (the watched problem of the host plug-in): the same kernels on a window [first, first + count) ----
+static BatchView window(const BatchView &b, size_t first, size_t count)
+{
+    BatchView w = b;
+    w.base = (char *)b.base + first * storage_size(b.dtype);
+    w.n = count;
+    return w;
+}
+
+hipError_t launch_soa_to_aos_range(const BatchView &b, size_t first, size_t count, double *d_aos, hipStream_t stream)
+{
+    return launch_soa_to_aos(window(b, first, count), d_aos, stream);
+}
+
+hipError_t launch_sample_range(const BatchView &b, size_t first, size_t count, double *d_pos66, double *d_acc4, hipStream_t stream)
+{
+    return launch_sample(window(b, first, count), d_pos66, d_acc4, stream);
+}
+
+hipError_t launch_constraint_table(const BatchView &b, const HostParams &hp, size_t first, size_t count, double *d_rows, hipStream_t stream)
+{
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_constraint_table<S, T, V>), dim3(grid_for(count)), dim3(kBlock), 0, stream,
+                                       (const S *)b.base, b.stride, first, count, make_kparams<T>(hp, V), d_rows));
     return hipGetLastError();
 }
 

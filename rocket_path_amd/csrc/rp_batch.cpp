@@ -26,6 +26,7 @@ struct rp_batch {
     double *d_scratch;        // [0..4095] block partials, [4096..4099] reduction result
     double *d_aos;            // lazily allocated n * state_len doubles
     double *d_pos;            // lazily allocated 3 * n doubles (set_problems staging)
+    double *d_range;          // lazily allocated kRangeChunk * kRangeRow doubles: staging of the *_range read-backs
     double ungated_steps;     // per-problem count of ungated steps since the last init
     unsigned long long *h_pinned;   // 72 pinned host words: [0,64) counter shards, [64,68) reduction: read-backs without pageable staging
     hipEvent_t events[8];
@@ -58,7 +59,11 @@ int fail(int status, const char *fmt, ...)
         RP_HIP(hipSetDevice((b)->device));                          \
     } while (0)
 
-size_t elem_size(int dtype) { return dtype == RP_DTYPE_F32 ? 4 : 8; }
+size_t elem_size(int dtype) { return rp::storage_size(dtype); }
+
+// The *_range calls (a watched problem, a page of a table) go through one small device buffer that lives as long as
+// the batch: kRangeChunk problems x the widest row (the F3 constraint table, 1 + 14 * 8 doubles) = 0.9 MB.
+constexpr size_t kRangeChunk = 1024, kRangeRow = 113;
 
 void default_params(rp::HostParams &hp)
 {
@@ -76,6 +81,19 @@ int reset_progress(rp_batch *b)
     b->ungated_steps = 0.0;
     RP_HIP(rp::launch_clear_progress(b->view, b->stream));
     RP_HIP(rp::launch_order(b->view, b->stream));     // every init path ends here: positions are final
+    return RP_OK;
+}
+
+int need_range(rp_batch *b)
+{
+    if (!b->d_range) RP_HIP(hipMalloc((void **)&b->d_range, kRangeChunk * kRangeRow * sizeof(double)));
+    return RP_OK;
+}
+
+int check_range(const rp_batch *b, size_t first, size_t count, const void *out)
+{
+    if (!out) return fail(RP_ERR_INVALID, "null output");
+    if (first > b->view.n || count > b->view.n - first) return fail(RP_ERR_INVALID, "range [%zu, %zu + %zu) outside the batch of %zu", first, first, count, b->view.n);
     return RP_OK;
 }
 
@@ -134,7 +152,8 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     if (!out) return fail(RP_ERR_INVALID, "out is null");
     *out = nullptr;
     if (variant != RP_VARIANT_F3 && variant != RP_VARIANT_F4) return fail(RP_ERR_INVALID, "variant %d (want 3 or 4)", variant);
-    if (dtype != RP_DTYPE_F64 && dtype != RP_DTYPE_F32) return fail(RP_ERR_INVALID, "dtype %d (want 0 = f64 or 1 = f32)", dtype);
+    if (dtype != RP_DTYPE_F64 && dtype != RP_DTYPE_F32 && dtype != RP_DTYPE_F32_STATE)
+        return fail(RP_ERR_INVALID, "dtype %d (want 0 = f64, 1 = f32 or 2 = f32 state with f64 arithmetic)", dtype);
     if (n == 0) return fail(RP_ERR_INVALID, "empty batch");
     int count = 0;
     int st = rp_device_count(&count);
@@ -191,6 +210,7 @@ int rp_batch_destroy(rp_batch *b)
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     if (b->d_aos) (void)hipFree(b->d_aos);
     if (b->d_pos) (void)hipFree(b->d_pos);
+    if (b->d_range) (void)hipFree(b->d_range);
     if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return RP_OK;
@@ -328,6 +348,22 @@ int rp_batch_get_state(rp_batch *b, double *aos)
     return RP_OK;
 }
 
+int rp_batch_get_state_range(rp_batch *b, size_t first, size_t count, double *aos)
+{
+    RP_NEED(b);
+    int st = check_range(b, first, count, aos);
+    if (st == RP_OK) st = need_range(b);
+    if (st != RP_OK) return st;
+    const size_t M = (size_t)rp::state_len(b->view.variant);
+    for (size_t done = 0; done < count; done += kRangeChunk) {
+        const size_t c = count - done < kRangeChunk ? count - done : kRangeChunk;
+        RP_HIP(rp::launch_soa_to_aos_range(b->view, first + done, c, b->d_range, b->stream));
+        RP_HIP(hipMemcpyAsync(aos + done * M, b->d_range, c * M * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        RP_HIP(hipStreamSynchronize(b->stream));      // the staging buffer is reused by the next chunk
+    }
+    return RP_OK;
+}
+
 int rp_batch_nudge(rp_batch *b, int var_index, double delta)
 {
     RP_NEED(b);
@@ -459,6 +495,40 @@ int rp_batch_sample(rp_batch *b, double *pos66, double *acc4)
     return RP_OK;
 }
 
+int rp_batch_sample_range(rp_batch *b, size_t first, size_t count, double *pos66, double *acc4)
+{
+    RP_NEED(b);
+    int st = check_range(b, first, count, pos66);
+    if (st == RP_OK && !acc4) st = fail(RP_ERR_INVALID, "null output");
+    if (st == RP_OK) st = need_range(b);
+    if (st != RP_OK) return st;
+    for (size_t done = 0; done < count; done += kRangeChunk) {
+        const size_t c = count - done < kRangeChunk ? count - done : kRangeChunk;
+        double *d_pos = b->d_range, *d_acc = b->d_range + kRangeChunk * 66;
+        RP_HIP(rp::launch_sample_range(b->view, first + done, c, d_pos, d_acc, b->stream));
+        RP_HIP(hipMemcpyAsync(pos66 + done * 66, d_pos, c * 66 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        RP_HIP(hipMemcpyAsync(acc4 + done * 4, d_acc, c * 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        RP_HIP(hipStreamSynchronize(b->stream));
+    }
+    return RP_OK;
+}
+
+int rp_batch_constraints_range(rp_batch *b, size_t first, size_t count, double *rows)
+{
+    RP_NEED(b);
+    int st = check_range(b, first, count, rows);
+    if (st == RP_OK) st = need_range(b);
+    if (st != RP_OK) return st;
+    const size_t row = 1 + 14 * (size_t)rp::num_constraints(b->view.variant);
+    for (size_t done = 0; done < count; done += kRangeChunk) {
+        const size_t c = count - done < kRangeChunk ? count - done : kRangeChunk;
+        RP_HIP(rp::launch_constraint_table(b->view, b->params, first + done, c, b->d_range, b->stream));
+        RP_HIP(hipMemcpyAsync(rows + done * row, b->d_range, c * row * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        RP_HIP(hipStreamSynchronize(b->stream));
+    }
+    return RP_OK;
+}
+
 int rp_batch_sync(rp_batch *b)
 {
     RP_NEED(b);
@@ -500,6 +570,11 @@ int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr)
     if (!b || !d_ptr) return fail(RP_ERR_INVALID, "null argument");
     if (field < 0 || field >= rp::state_len(b->view.variant)) return fail(RP_ERR_INVALID, "field %d out of range", field);
     *d_ptr = (char *)b->view.base + (size_t)field * b->view.stride * elem_size(b->view.dtype);
+    {   // a caller holding a raw pointer to an end-velocity field may write non-zero values the batch never sees: from
+        // here on (until the next init / set_problems / set_state) the Newton kernels read vel0X and vel2X
+        const int iv0 = 3 + rp::num_constraints(b->view.variant) + 1, iv2 = iv0 + 3;
+        if (field == iv0 || field == iv2) b->view.zero_end_vel = false;
+    }
     return RP_OK;
 }
 

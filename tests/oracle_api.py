@@ -114,6 +114,11 @@ class Oracle:
         self.lib.orc_constraint(variant, i, _p(np.ascontiguousarray(var, dtype=np.float64)), _p(e), _p(g))
         return e[0], g
 
+    def constraint_hess(self, variant, i, var):
+        h = np.zeros(9)
+        self.lib.orc_constraint_hess(variant, i, _p(np.ascontiguousarray(var, dtype=np.float64)), _p(h))
+        return h
+
     def satisfied(self, variant, var):
         return bool(self.lib.orc_constraints_satisfied(variant, _p(np.ascontiguousarray(var, dtype=np.float64))))
 

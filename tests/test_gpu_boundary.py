@@ -1,0 +1,158 @@
+"""The drop-in boundary beyond the step itself: range read-backs (the watched problem of the host plug-in), the
+printState text, redisplay after handled keys, and the end-velocity guard of rp_batch_field_ptr.
+
+Reference behaviour mirrored: printState / printConstraints (onedpath_ip.cpp:955-1010, onedpath2_ip.cpp:843-918),
+repaint() after every handled key (onedpath_ip.cpp:250-324), onDraw once per posted redisplay
+(rocket_path.cpp:101-106, 178-182)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import rocket_path_amd as rp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "rocket_path_amd", "lib", "rp_headless")
+
+
+def serr(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+
+
+@pytest.mark.parametrize("variant,dtype", [(rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F32)])
+def test_range_readbacks_equal_the_whole_batch_readbacks(variant, dtype):
+    n = 5000                                   # > one 1024-problem staging chunk, ragged
+    p0, p1, p2 = rp.problems.generate(8, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n, variant, dtype) as b:
+        b.set_problems(p0, p1, p2)
+        b.step(3)
+        st = b.get_state()
+        pos, acc = b.sample()
+        for first, count in ((0, 1), (n - 1, 1), (1023, 2), (17, 2500), (0, n)):
+            assert np.array_equal(b.get_state_range(first, count), st[first:first + count])
+            p, a = b.sample_range(first, count)
+            assert np.array_equal(p, pos[first:first + count]) and np.array_equal(a, acc[first:first + count])
+        assert b.get_state_range(n, 0).shape == (0, b.state_len)
+        for first, count in ((n, 1), (0, n + 1), (n + 5, 0)):
+            with pytest.raises(rp.RpError):
+                b.get_state_range(first, count)
+            with pytest.raises(rp.RpError):
+                b.sample_range(first, count)
+            with pytest.raises(rp.RpError):
+                b.constraints_range(first, count)
+
+
+@pytest.mark.parametrize("variant", [rp.VARIANT_F3, rp.VARIANT_F4])
+def test_constraint_table_against_oracle(oracle, variant):
+    n = 1500
+    p0, p1, p2 = rp.problems.generate(21, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n, variant) as b:
+        b.set_problems(p0, p1, p2)
+        b.step(4)
+        st = b.get_state()
+        gap, tab = b.constraints_range(0, n)
+    m = b.num_constraints
+    for i in range(0, n, 13):
+        assert abs(gap[i] - oracle.gap(variant, st[i])) <= 1e-12 * max(1.0, abs(gap[i]))
+        for c in range(m):
+            err, grad = oracle.constraint(variant, c, st[i])
+            hess = oracle.constraint_hess(variant, c, st[i])
+            scale = max(1.0, abs(err))
+            assert abs(tab[i, c, 0] - err) <= 1e-12 * scale
+            assert serr(tab[i, c, 1:4], grad) < 1e-12
+            assert np.max(np.abs(tab[i, c, 4:13] - hess)) <= 1e-12 * max(1.0, np.max(np.abs(hess)))
+            assert abs(tab[i, c, 13] + grad[1] + grad[2]) <= 1e-12 * max(1.0, abs(grad[1] + grad[2]))
+    if variant == rp.VARIANT_F4:     # the reference never writes the (vel1X, vel1X) second derivative (onedpath2_ip.cpp:446-448)
+        assert np.all(tab[:, :, 4] == 0.0)
+
+
+def test_print_state_is_the_references_text_for_the_watched_problem(oracle):
+    # the default problem after one step: every number the reference's printState shows, for lane 3 of 7
+    out = subprocess.run([EXE, "--n", "7", "--watch", "3", "--keys", "i n s"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    v = oracle.init_default(3)
+    oracle.step(3, v)
+    text = out.stdout[out.stdout.index("Node 0:"):]
+    lines = text.splitlines()
+    assert lines[0] == "Node 0: pos=%g vel=%g" % (v[11], v[12])
+    assert lines[1] == "Node 1: pos=%g vel=%g" % (v[13], v[0])
+    assert lines[2] == "Node 2: pos=%g vel=%g" % (v[14], v[15])
+    assert lines[3] == "Duration 0: %g" % v[1] and lines[4] == "Duration 1: %g" % v[2]
+    assert lines[5] == "Constraint Multipliers:" + "".join(" %g" % x for x in v[3:11])
+    assert lines[6] == "Surrogate gap: %g" % oracle.gap(3, v)
+    assert lines[7] == "Constraints:"
+    for c in range(8):
+        err, grad = oracle.constraint(3, c, v)
+        h = oracle.constraint_hess(3, c, v).reshape(3, 3)
+        exp = "%c%u: error=%g derivs=[%s] second=[%s] dot=%g" % (
+            "*" if err > 0 else " ", c, err, " ".join("%g" % g for g in grad),
+            " ".join("[" + " ".join("%g" % x for x in row) + "]" for row in h), -(grad[1] + grad[2]))
+        unsigned_zero = lambda t: re.sub(r"-0(?![.\d])", "0", t)      # noqa: E731  (%g prints -0 for a negated 0 entry)
+        assert unsigned_zero(lines[8 + c]) == unsigned_zero(exp), c
+    assert lines[16].startswith("Batch: 7 problems")
+
+
+def test_f4_print_state_has_the_column_header():
+    out = subprocess.run([EXE, "--n", "2", "--f4", "--keys", "s"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "[v1 t0 t1] [[v1/v1 v1/t0 v1/t1] [t0/v1 t0/t0 t0/t1] [t1/v1 t1/t0 t1/t1]]" in out.stdout
+    assert len(re.findall(r"^[ *]\d: error=", out.stdout, flags=re.M)) == 4
+
+
+def test_handled_keys_repaint_and_ondraw_fetches_only_the_watched_problem(oracle):
+    # i, n, SPACE, HOME, F4 (switch) and n again are handled -> six redisplays; 's' and an unknown special key are not
+    n = 1 << 16
+    out = subprocess.run([EXE, "--n", str(n), "--seed", "7", "--watch", "4242", "--keys", "i n SPACE HOME s p F4 n"],
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr
+    assert "redraws: 6" in out.stderr
+    plot = [l for l in out.stdout.splitlines() if l.startswith("Plot:")][0]
+    pos_s, acc_s = plot[len("Plot:"):].split("|")
+    pos = np.array(pos_s.split(), dtype=float)
+    acc = np.array(acc_s.split(), dtype=float)
+    assert pos.shape == (66,) and acc.shape == (4,)
+    # the shell's 'i' re-inits to the default problem, so the plot is the default problem after n, SPACE, HOME
+    v = oracle.init_default(3)
+    oracle.step(3, v)
+    oracle.move_toward_feasibility(3, v)
+    v[1] += 0.1
+    p, a = oracle.sample(3, v)
+    assert serr(pos, p) < 1e-12 and serr(acc, a) < 1e-12
+
+
+def test_field_ptr_to_an_end_velocity_selects_the_general_kernels(oracle):
+    # a caller that writes vel0X / vel2X through the raw pointer must not be stepped by the
+    # zero-end-velocity instantiation
+    rp.load_library()
+    # the HIP runtime the product library runs on (torch, if some other test imported it, brings a second copy)
+    paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}, key=lambda p: "torch" in p)
+    hip_path = paths[0]
+    hip = ctypes.CDLL(hip_path)
+    n = 512 * 512 + 9                           # large enough for the tiled kernels
+    p0, p1, p2 = rp.problems.generate(77, 0, n, rp.problems.DIST_MONOTONE)
+    v0 = np.linspace(-0.05, 0.05, n)
+    v2 = np.linspace(0.04, -0.04, n)
+    with rp.Batch(n) as b:
+        b.set_problems(p0, p1, p2)
+        for field, vals in ((12, v0), (15, v2)):
+            ptr = b.field_ptr(field)
+            assert hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(vals.ctypes.data), ctypes.c_size_t(n * 8), 1) == 0
+        st0 = b.get_state()
+        assert np.array_equal(st0[:, 12], v0) and np.array_equal(st0[:, 15], v2)
+        b.step(5)
+        out = b.get_state()
+    sl = slice(1000, 1000 + 2048)
+    exp = st0[sl].copy()
+    oracle.batch_steps(3, exp, 5)
+    assert serr(out[sl, :3], exp[:, :3]) < 1e-10
+    zero = st0[sl].copy()
+    zero[:, 12] = 0.0
+    zero[:, 15] = 0.0
+    oracle.batch_steps(3, zero, 5)
+    assert serr(out[sl, :3], zero[:, :3]) > 1e-6      # the velocities matter: the ZV instantiation would have given this

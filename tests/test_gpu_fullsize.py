@@ -74,6 +74,32 @@ def test_config5_f4_fp32_one_million_runs_and_stays_finite():
     assert np.max(np.abs(acc)) <= 100.0 * (1 + 1e-4)      # the line search never accepts an infeasible point
 
 
+def test_config5_f4_fp32_state_one_million_one_step_against_the_fp64_oracle(oracle):
+    # config 5 at full size, per-problem bound: after 10 steps of the 1 Mi batch (fp32 state, fp64 arithmetic) take one
+    # more step and compare a 64k slice with the fp64 oracle stepping from the identical (fp32-representable) states
+    n = 1 << 20
+    p0, p1, p2 = rp.problems.generate(12345, 0, n, rp.problems.DIST_MONOTONE)
+    sl = slice(300000, 300000 + 65536)
+    with rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32_STATE) as b:
+        b.set_problems(p0, p1, p2)
+        b.step(10)
+        before = b.get_state_range(sl.start, 65536)
+        b.step(1)
+        after = b.get_state_range(sl.start, 65536)
+        b.step(39)
+        st = b.get_state()
+        pos, acc = b.sample_range(0, 1 << 16)
+    assert np.array_equal(before, before.astype(np.float32).astype(np.float64))
+    exp = before.copy()
+    oracle.batch_steps(4, exp, 1)
+    err = np.abs(after[:, :3] - exp[:, :3]) / np.maximum(np.abs(exp[:, :3]), 1.0)
+    assert err.max() < 1.0e-7, err.max()
+    scale = np.max(np.abs(exp[:, 3:7]), axis=1, keepdims=True)
+    assert np.max(np.abs(after[:, 3:7] - exp[:, 3:7]) / scale) < 1.0e-7
+    assert np.all(np.isfinite(st)) and np.all(st[:, 1] > 0) and np.all(st[:, 2] > 0)
+    assert np.max(np.abs(acc)) <= 100.0 * (1 + 1e-6)      # feasible up to the rounding of the state to fp32
+
+
 def test_mirror_symmetry_property():
     # Reflecting a problem (p0,p1,p2) -> (-p2,-p1,-p0) swaps the two segments: the optimum has the same
     # midpoint velocity and swapped durations.  The arithmetic is not symmetric (seg 0 and seg 1 are

@@ -30,8 +30,8 @@ def test_tiled_kernels_fit_three_waves_without_scratch():
         m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", line)
         if m and name:
             usage[name][m.group(1)] = int(m.group(2))
-    # k_solve_tiled<double, 3, GATED, STALL=false, ZV=true>: the benchmark's kernel and its ungated sibling
-    tiled = {k: v for k, v in usage.items() if "k_solve_tiledIdLi3ELb" in k and k.split("k_solve_tiledIdLi3")[1].startswith(("ELb1ELb0ELb1", "ELb0ELb0ELb1"))}
+    # k_solve_tiled<S=double, T=double, 3, GATED, STALL=false, ZV=true>: the benchmark's kernel and its ungated sibling
+    tiled = {k: v for k, v in usage.items() if "k_solve_tiledIddLi3ELb" in k and k.split("k_solve_tiledIddLi3")[1].startswith(("ELb1ELb0ELb1", "ELb0ELb0ELb1"))}
     assert len(tiled) == 2, sorted(usage)
     for k, v in tiled.items():
         assert v["VGPRs"] <= 168, (k, v)
