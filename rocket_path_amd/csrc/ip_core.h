@@ -158,7 +158,8 @@ template <> struct CMap<4> { static constexpr int NC = 4; };   // onedpath2_ip.c
 template <typename T, class P>
 __device__ __forceinline__ void accel_values(const P &k, T v, T t0, T t1, Acc<T> &e)
 {
-    const T r0 = rcp_(t0), r1 = rcp_(t1);
+    const T rr = rcp_(t0 * t1);                               // one reciprocal for both durations: 1/t0 = t1/(t0 t1)
+    const T r0 = t1 * rr, r1 = t0 * rr;
     e.r0 = r0;
     e.r1 = r1;
     const T u0 = k.dx0 * r0, u1 = k.dx1 * r1;                 // dX / t
@@ -272,7 +273,11 @@ template <typename T, int VARIANT, bool TRIAL>
 __device__ __forceinline__ T residual_norm(const Acc<T> &e, const T (&lam)[CMap<VARIANT>::NC],
                                            const T (&dl)[CMap<VARIANT>::NC], T s, T p, T L)
 {
-    T rv = T(0), rt0 = T(1), rt1 = T(1), acc = T(0);
+    // The sum of squares runs in independent partial sums (the constraints' minus and plus halves, then the three
+    // gradient terms): a lone wave on a SIMD -- the post-convergence regime of a fixed-step run -- is bound by the
+    // latency of a dependent chain, not by issue.  Every caller goes through this one function, so the r(x) a step
+    // starts from and the r(x + s d) it is compared with are rounded alike.
+    T rv = T(0), rt0 = T(1), rt1 = T(1), accm = T(0), accp = T(0);
     if constexpr (VARIANT == 3) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -284,8 +289,8 @@ __device__ __forceinline__ T residual_norm(const Acc<T> &e, const T (&lam)[CMap<
             else       rt1 = fma_(d, e.gt[j], rt1);
             const T rm = fma_(lm, -e.a[j] - L, p);
             const T rp = fma_(lp, e.a[j] - L, p);
-            acc = fma_(rm, rm, acc);
-            acc = fma_(rp, rp, acc);
+            accm = fma_(rm, rm, accm);
+            accp = fma_(rp, rp, accp);
         }
     } else {
 #pragma unroll
@@ -297,13 +302,12 @@ __device__ __forceinline__ T residual_norm(const Acc<T> &e, const T (&lam)[CMap<
             if (i < 2) rt0 = fma_(li, gt, rt0);
             else       rt1 = fma_(li, gt, rt1);
             const T rc = fma_(li, c_value<T, 4>(i, e, L), p);
-            acc = fma_(rc, rc, acc);
+            if (i & 1) accp = fma_(rc, rc, accp);
+            else       accm = fma_(rc, rc, accm);
         }
     }
-    acc = fma_(rv, rv, acc);
-    acc = fma_(rt0, rt0, acc);
-    acc = fma_(rt1, rt1, acc);
-    return acc;
+    const T accx = fma_(rt1, rt1, fma_(rt0, rt0, rv * rv));
+    return (accm + accp) + accx;
 }
 
 // 3x3 solve, Gaussian elimination with partial pivoting (row of largest magnitude, first
@@ -361,14 +365,17 @@ template <typename T> __device__ __forceinline__ T c_guard(T c, T c_floor) { ret
 // zero).  d and e are eliminated first when they pass the Bunch-Kaufman 1x1 pivot test
 // |pivot| >= alpha * |off-diagonal of its column|, alpha = (1 + sqrt 17)/8 -- bounded growth, the
 // symmetric counterpart of partial pivoting -- which they do in all but the early, indefinite
-// iterations; otherwise the general partial-pivot elimination runs.  The branch is per lane; a
-// wave pays for both paths only while one of its lanes is in the indefinite regime.
+// iterations; otherwise (or when a pivot is zero, or their product leaves the number range) the general
+// partial-pivot elimination runs.  The branch is per lane; a wave pays for both paths only while one of its
+// lanes is in the indefinite regime.
 template <typename T>
 __device__ __forceinline__ void solve_arrow(T a, T b, T c, T d, T e, T rv, T r0, T r1, T &xv, T &x0, T &x1)
 {
     const T alpha = T(0.6403882032022076);
-    if (abs_(d) >= alpha * abs_(b) && abs_(e) >= alpha * abs_(c)) {
-        const T id = srcp_(d), ie = srcp_(e);
+    const T de = d * e;
+    if (abs_(d) >= alpha * abs_(b) && abs_(e) >= alpha * abs_(c) && de != T(0) && finite_(de)) {
+        const T ide = rcp_(de);                              // one reciprocal for both pivots: 1/d = e/(d e)
+        const T id = e * ide, ie = d * ide;
         const T lb = b * id, lc = c * ie;
         const T sc = fma_(-lb, b, fma_(-lc, c, a));          // Schur complement on vel1
         const T rs = fma_(-lb, r0, fma_(-lc, r1, rv));
@@ -393,14 +400,32 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
     T bv = T(0), b0 = T(-1), b1 = T(-1);
 
     if constexpr (VARIANT == 3) {
+        // 1/cm_j and 1/cp_j for the four accelerations from ONE reciprocal: with x_j = cm_j cp_j (= L^2 - a_j^2 > 0 inside
+        // the feasible set) 1/(x0 x1 x2 x3) gives every 1/x_j by two multiplications, and 1/cm = cp/x, 1/cp = cm/x.  A
+        // v_rcp_f64 with its two Newton steps costs what seven multiplications cost.  x_j ranges over [L^2 eps/128, 4 L^2]
+        // for feasible points, so the product of four stays far inside the double range.
         T icm[4], icp[4];
+        {
+            T cm[4], cp[4], x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cm[j] = c_guard(-e.a[j] - L, kp.c_floor);
+                cp[j] = c_guard(e.a[j] - L, kp.c_floor);
+                x[j] = cm[j] * cp[j];
+            }
+            const T x01 = x[0] * x[1], x23 = x[2] * x[3];
+            const T iall = rcp_(x01 * x23);
+            const T i01 = x23 * iall, i23 = x01 * iall;
+            const T ix[4] = {x[1] * i01, x[0] * i01, x[3] * i23, x[2] * i23};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                icm[j] = cp[j] * ix[j];
+                icp[j] = cm[j] * ix[j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const T lm = lam[2 * j], lp = lam[2 * j + 1];
-            const T cm = c_guard(-e.a[j] - L, kp.c_floor), cp = c_guard(e.a[j] - L, kp.c_floor);
-            const T ipr = rcp_(cm * cp);          // 1/cm = cp/(cm cp), 1/cp = cm/(cm cp)
-            icm[j] = cp * ipr;
-            icp[j] = cm * ipr;
             const T w = fma_(lm, icm[j], lp * icp[j]);      // lm/cm + lp/cp
             const T q = p * (icp[j] - icm[j]);              // rhs weight of grad a_j
             const T d = lp - lm;
@@ -427,11 +452,18 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
             dl[2 * j + 1] = fma_(-icp[j], fma_(lp, da, p), -lp);       // -lp - (lp da + p)/cp
         }
     } else {
-        T w[4], pc[4], gv[4], gt[4];
+        T w[4], pc[4], gv[4], gt[4], icv[4];
+        {   // the four 1/c_i from two reciprocals (pairwise: single precision has no range for a product of four)
+            T cg[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cg[i] = c_guard((e.a[i] * e.a[i] - L * L) * T(0.5), kp.c_floor * L);
+            const T i01 = rcp_(cg[0] * cg[1]), i23 = rcp_(cg[2] * cg[3]);
+            icv[0] = cg[1] * i01; icv[1] = cg[0] * i01; icv[2] = cg[3] * i23; icv[3] = cg[2] * i23;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const T a = e.a[i];
-            const T ic = rcp_(c_guard((a * a - L * L) * T(0.5), kp.c_floor * L));
+            const T ic = icv[i];
             gv[i] = a * acc_gv(e, i);
             gt[i] = a * e.gt[i];
             w[i] = lam[i] * ic;
@@ -465,7 +497,12 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
 // ---- one Newton step -------------------------------------------------------------------
 // In:  x = (v, t0, t1), lam, c = reciprocals + accelerations at x, gap = surrogate duality gap at x.
 // Out: the same at the new point (the caller recomputes the gap from c).
-template <typename T, int VARIANT, class P>
+//
+// MEMO: exact memoisation of evaluations at trial points that are bitwise the current point.  It changes no result
+// (the reference recomputes the same numbers); what it buys is the reference's post-convergence regime, where x no
+// longer moves and every step still walks ~48 residual halvings (onedpath_ip.cpp:932-945) -- fixed-step runs.  A gated
+// solve stops long before that regime, so its kernels are built without the checks.
+template <typename T, int VARIANT, class P, bool MEMO = true>
 __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
                                             T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T> &c)
 {
@@ -474,26 +511,34 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     const T p = gap * kp.inv_mu_den;                      // onedpath_ip.cpp:812
 
     T dxv, dx0, dx1, dl[NC], r0n;
-    bool feasible_here;
+    bool feasible_here = true;
     {
         Acc<T> e;
         e.r0 = c.r0; e.r1 = c.r1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) e.a[j] = c.a[j];
         accel_grads(k, v, e);
-        feasible_here = all_satisfied<T, VARIANT>(e, L);
+        if constexpr (MEMO) feasible_here = all_satisfied<T, VARIANT>(e, L);
         direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
         r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);      // onedpath_ip.cpp:932
     }
 
-    // -- fraction to the boundary on the multipliers (onedpath_ip.cpp:903-915) --
-    T s = T(1);
+    // -- fraction to the boundary on the multipliers (onedpath_ip.cpp:903-915): s = min(1, min_{dl_i < 0} -lam_i/dl_i).
+    // The smallest ratio is found on cross-multiplied pairs (lam_i / e_i < nb / eb  <=>  lam_i eb < nb e_i for
+    // positive denominators; a non-negative dl_i gives e_i <= 0 and never wins, a NaN compares false and is skipped as
+    // std::min skips it) and divided once, instead of eight divisions and a running minimum.
+    T s;
+    {
+        T nb = T(1), eb = T(1);
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const T q = (dl[i] < T(0)) ? -lam[i] * rcp1_(dl[i]) : T(1);
-        s = min_(s, q);                                   // std::min(s, q): a NaN q leaves s
+        for (int i = 0; i < NC; ++i) {
+            const T ei = -dl[i];
+            const bool take = lam[i] * eb < nb * ei;
+            nb = take ? lam[i] : nb;
+            eb = take ? ei : eb;
+        }
+        s = (nb * rcp1_(eb)) * kp.boundary;
     }
-    s *= kp.boundary;
 
     // -- backtrack until primal feasible (onedpath_ip.cpp:919-928) --
     Acc<T> et;                 // evaluation at the current trial point
@@ -504,7 +549,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         tt0 = fma_(dx0, s, t0);
         tt1 = fma_(dx1, s, t1);
         bool ok;
-        if (tv == v && tt0 == t0 && tt1 == t1) {
+        if (MEMO && tv == v && tt0 == t0 && tt1 == t1) {
             ok = feasible_here;            // same point, same answer
             et_valid = false;
         } else {
@@ -518,39 +563,41 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     }
 
     // -- backtrack until the residual decreases (onedpath_ip.cpp:932-945) --
-    // The loop works in `et` only.  When a trial point is bitwise x, the evaluation at x is rebuilt in `et`
-    // from the carried reciprocals and accelerations -- bit for bit what the step started from.
     bool accepted = false;         // et = values at the point the loop broke on
-    for (int it = 0; it < kp.max_bt; ++it) {
+    int it = 0;
+    bool frozen = false;           // the trial point has become bitwise x (and stays so: s only shrinks)
+    for (; it < kp.max_bt; ++it) {
         tv = fma_(dxv, s, v);
         tt0 = fma_(dx0, s, t0);
         tt1 = fma_(dx1, s, t1);
-        const bool same_x = (tv == v && tt0 == t0 && tt1 == t1);
-        T rn;
-        if (same_x) {
-            bool same_l = true;     // only worth asking once the step no longer moves x (stalled regime)
-#pragma unroll
-            for (int i = 0; i < NC; ++i) same_l = same_l && (fma_(dl[i], s, lam[i]) == lam[i]);
-            et.r0 = c.r0; et.r1 = c.r1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) et.a[j] = c.a[j];
-            if (same_l) {
-                rn = r0n;
-            } else {
-                accel_grads(k, v, et);
-                rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
-            }
-        } else {
-            if (!et_valid) accel_values(k, tv, tt0, tt1, et);
-            accel_grads(k, tv, et);
-            rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
-        }
+        if (MEMO && tv == v && tt0 == t0 && tt1 == t1) { frozen = true; break; }
+        if (!et_valid) accel_values(k, tv, tt0, tt1, et);
+        accel_grads(k, tv, et);
+        const T rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
         et_valid = false;
         if (rn <= r0n * (T(1) - kp.armijo * s)) {
             accepted = true;
             break;
         }
         s *= kp.backtrack;
+    }
+    if constexpr (MEMO) {
+        if (frozen) {
+            // x + s dx == x from here on: the evaluation at x (bit for bit what the step started from) is loop-invariant,
+            // only the multipliers lam + s dl still depend on s.  What is left per halving is the sum of squares itself.
+            et.r0 = c.r0; et.r1 = c.r1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) et.a[j] = c.a[j];
+            accel_grads(k, v, et);
+            for (; it < kp.max_bt; ++it) {
+                const T rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
+                if (rn <= r0n * (T(1) - kp.armijo * s)) {
+                    accepted = true;
+                    break;
+                }
+                s *= kp.backtrack;
+            }
+        }
     }
 
     // -- take the step (onedpath_ip.cpp:949-952) --

@@ -103,7 +103,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                 else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
             }
         }
-        newton_step<T, VARIANT, P>(pr, kp, gap, v, t0, t1, lam, e);
+        newton_step<T, VARIANT, P, !GATED>(pr, kp, gap, v, t0, t1, lam, e);      // gated solves never reach the regime the memoisation is for
         if constexpr (sizeof(S) != sizeof(T)) {
             v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
 #pragma unroll
