@@ -17,11 +17,14 @@ N > 1: one process per GPU, rank r owns the contiguous shard r of the N x 1,048,
 (weak scaling); no step exchanges anything; the only collective is the final 32-byte summary
 all-reduce over RCCL.
 
-Printed by rank 0: ONE JSON line (contract in the task statement), with `roofline` for the
-dominant kernel (k_solve_tiled<double,3>), `cpu_baseline` (oracle port, N = 1 only) and three
-labelled extras: `per_step_launch` (the same step as one launch per Newton step, which is the
-HBM-streaming form: 216 B really cross HBM per step), `fixed50` (configs[1]) and `f4_fp32`
-(configs[4]).
+Printed by rank 0: ONE JSON line (contract in the task statement).  `roofline` prices the timed kernel
+(k_solve_tiled<double, F3>, the fused gated solve) against the roof that binds it, the fp64 vector ALU, and
+carries the SURVEY 8d algorithmic-HBM figure as the labelled secondary `hbm_algorithmic` (a fused launch moves each
+state across HBM once per solve, not once per step).  `cpu_baseline` = the oracle port on the host cores (N = 1
+only).  Labelled extras: `per_step_launch` (one launch per Newton step, the form in which the bytes really cross
+HBM per step, priced on the bytes that move, next to two ceilings measured in the same run), `fixed50`
+(configs[1]) and `f4_fp32` (configs[4], both arithmetic modes, each with its own roofline).  Numbers that are read
+from committed rocprofv3 summaries instead of being measured in this run say so in a `source` key.
 """
 import argparse
 import json
@@ -39,7 +42,25 @@ SEED = 12345
 GAP_TOL = 1e-8
 MAX_ITER = 200
 B_ALG_F3 = 216.0          # bytes per problem per Newton step: read 16, write 11 doubles
+B_MOVED_F3_ZV = 200.0     # what the zero-end-velocity kernels really move per step: read 14, write 11 doubles
+B_ALG_F4_F32 = 76.0       # F4 fp32: read 12, write 7 floats; the zero-end-velocity kernels read 10: 68 B
+B_MOVED_F4_F32_ZV = 68.0
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6   # fp64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FP32_PEAK_TFLOPS = 157.3  # fp32 vector peak, same guide
+PROFILE_TAG = "r2"        # profiles/<tag>_*.json hold the rocprofv3 counter summaries the file-sourced numbers come from
+
+
+def profile_number(fname, *keys):
+    """A number from a committed rocprofv3 summary under profiles/ (None if absent), with the path it came from."""
+    path = os.path.join(ROOT, "profiles", fname)
+    try:
+        v = json.load(open(path))
+        for k in keys:
+            v = v[k]
+        return float(v), "profiles/" + fname
+    except Exception:
+        return None, None
 
 
 def cpu_quota():
@@ -63,10 +84,15 @@ def cpu_baseline(sample_n):
     orc = Oracle()
     threads = min(orc.hw_threads(), cpu_quota())
     p0, p1, p2 = problems.generate(SEED, 0, sample_n, problems.DIST_MONOTONE)
-    aos = orc.batch_init_feasible(3, p0, p1, p2)
-    t0 = time.perf_counter()
-    _, total = orc.batch_solve_gated(3, aos, GAP_TOL, MAX_ITER, threads=threads)
-    dt = time.perf_counter() - t0
+    # bounded sample: whole passes over the first sample_n problems of the batch until about 10 s of wall time are spent
+    total, dt, passes = 0, 0.0, 0
+    while dt < 10.0 and passes < 64:
+        aos = orc.batch_init_feasible(3, p0, p1, p2)
+        t0 = time.perf_counter()
+        _, tot = orc.batch_solve_gated(3, aos, GAP_TOL, MAX_ITER, threads=threads)
+        dt += time.perf_counter() - t0
+        total += tot
+        passes += 1
     # single-core rate on a smaller slice, for the per-core figure
     n1 = max(1, sample_n // 32)
     aos1 = orc.batch_init_feasible(3, p0[:n1], p1[:n1], p2[:n1])
@@ -74,7 +100,8 @@ def cpu_baseline(sample_n):
     _, total1 = orc.batch_solve_gated(3, aos1, GAP_TOL, MAX_ITER, threads=1)
     dt1 = time.perf_counter() - t0
     out = {"value": total / dt, "unit": "Newton steps/s", "cores": threads, "kind": "port",
-           "sample": "first %d problems of the same batch, same gate, %d steps in %.2f s on %d threads" % (sample_n, total, dt, threads),
+           "sample": "%d pass(es) over the first %d problems of the same batch, same gate: %d steps in %.2f s on %d threads" % (
+               passes, sample_n, total, dt, threads),
            "single_core_value": total1 / dt1}
     # the same restatement with its 11x11 solve done by the reference's own vendored Eigen 3.3.0 QR (oracle/_ref,
     # prebuilt where /root/reference exists): 78 % of a reference step is that call
@@ -212,14 +239,12 @@ def main():
         return
 
     steps_per_launch = steps_local / max(K, 1)
-    achieved = B_ALG_F3 * steps_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("k_solve_tiled_f3_f64", {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    alg_gbs = B_ALG_F3 * steps_per_launch / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = profile_number(PROFILE_TAG + "_hbm_traffic.json", "k_solve_tiled_f3_f64", "hbm_bytes_per_launch")
+    flop_per_step, flop_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_flop_per_newton_step")
+    if flop_per_step is None:
+        flop_per_step, flop_src = 560.0, "estimate (no profiles/%s_sq_counters.json)" % PROFILE_TAG
+    tflops = flop_per_step * steps_per_launch / (kernel_ms * 1e-3) / 1e12
     line = {
         "metric": "interior-point Newton steps/sec (whole node) + achieved HBM GB/s, 1M-problem batch",
         "value": steps_all / elapsed,
@@ -246,32 +271,26 @@ def main():
             "sharding": "contiguous shards, no data-path collective; one 32-byte RCCL all-reduce at the end" if world > 1
                         else "single GPU",
         },
+        # The roof that binds the timed kernel.  The fused solve keeps a problem's state in VGPRs from its first step to
+        # its gate and is fp64-VALU bound (VALU busy ~1.0 across the resident waves): flop per Newton step from the
+        # rocprofv3 SQ counters (2 x FMA + MUL + ADD + TRANS wave-instructions of an all-lanes-active launch, per lane-step).
         "roofline": {
-            "bound": "hbm", "kernel": "k_solve_tiled<double, F3> (fused gated solve: state stays in VGPRs between steps)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": B_ALG_F3 * steps_per_launch,
-            "avg_launch_ms": kernel_ms,
-            "note": "algorithmic bytes = 216 B x Newton steps executed in the launch (SURVEY.md 8d); the fused launch "
-                    "moves each state across HBM once per solve, so measured traffic is ~1/15 of this and the kernel "
-                    "is fp64-ALU bound; see per_step_launch for the form in which 216 B/step really cross HBM",
+            "bound": "fp64_valu", "kernel": "k_solve_tiled<double, double, F3, gated> (fused gated solve)",
+            "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
+            "flop_per_newton_step": flop_per_step, "flop_per_newton_step_source": flop_src,
+            "avg_launch_ms": kernel_ms, "newton_steps_per_launch": steps_per_launch,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "note": "idle lane-steps of the gated solve (~5 %) are not counted as flops; traffic = HBM bytes per launch from "
+                    "FETCH_SIZE (x2, calibrated) + WRITE_SIZE: each state crosses HBM once per solve",
+            # SURVEY 8d's definition, kept as a labelled secondary: algorithmic bytes (216 B x Newton steps executed in
+            # the launch) / launch time.  Not a fraction of anything for a fused launch -- see per_step_launch.
+            "hbm_algorithmic": {
+                "bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "ratio_to_peak": alg_gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": B_ALG_F3 * steps_per_launch,
+                "note": "can exceed 1: the fused launch moves ~1/15 of these bytes (traffic above)",
+            },
         },
     }
-
-    # The fused solve is fp64-ALU bound, so next to the (algorithmic) HBM roofline the same launch is priced against
-    # the fp64 vector peak: flop per Newton step from the rocprofv3 SQ counters of profiles/r1_sq_counters.json
-    # (2 x FMA + MUL + ADD + RCP wave-instructions of the ungated 12-step launch, per lane-step).
-    FLOP_PER_STEP, FP64_PEAK_TFLOPS = 643.0, 78.6
-    try:
-        FLOP_PER_STEP = float(json.load(open(os.path.join(ROOT, "profiles", "r1_sq_counters.json")))["_flop_per_newton_step"])
-    except Exception:
-        pass
-    tflops = FLOP_PER_STEP * steps_per_launch / (kernel_ms * 1e-3) / 1e12
-    line["compute_roofline"] = {"bound": "fp64 vector ALU", "flop_per_newton_step": FLOP_PER_STEP, "achieved": tflops,
-                                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
-                                "note": "about 490 VALU instructions per step, 400 of them fp64; measured issue cost 2.1 ns per fp64 "
-                                        "wave-instruction per SIMD (profiles/probes/valu_probe.hip); idle lane-steps of the gated "
-                                        "solve (~10 %) are not counted as flops"}
 
     if not args.no_extras:
         # (a) one launch per Newton step: the HBM-streaming form of the same step (216 B really move per step).
@@ -309,14 +328,39 @@ def main():
         lead.event_record(3)
         lead.sync()
         ms_warm = lead.event_elapsed_ms(2, 3) / len(spare)
-        gbs = lambda ms: B_ALG_F3 * count / (ms * 1e-3) / 1e9   # noqa: E731
+        # box ceiling in the same run: a plain 16 B/lane device copy moving the bytes one k = 1 launch moves
+        # (100 MiB in, 100 MiB out), every pair of buffers touched once
+        nel = int(B_MOVED_F3_ZV * count / 2 / 8)
+        pairs = [(torch.empty(nel, dtype=torch.float64, device=torch.device("cuda", local_rank)).fill_(1.0),
+                  torch.empty(nel, dtype=torch.float64, device=torch.device("cuda", local_rank))) for _ in range(8)]
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for src, dst in pairs:
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_copy = e0.elapsed_time(e1) / len(pairs)
+        del pairs
+        moved = lambda ms: B_MOVED_F3_ZV * count / (ms * 1e-3) / 1e9   # noqa: E731
+        k1_traffic, k1_src = profile_number(PROFILE_TAG + "_hbm_traffic.json", "k_newton_stream16_f3_f64", "hbm_bytes_per_launch")
         line["per_step_launch"] = {
-            "kernel": "k_newton_stream<double, F3>, k = 1 (register-prefetched, grid = resident set)",
+            "kernel": "k_newton_stream16<double, double, F3, zero end velocities>, k = 1: one launch per Newton step, 16 B per lane "
+                      "(two problems per lane)",
             "avg_launch_ms": ms_cold, "newton_steps_per_s": count / (ms_cold * 1e-3),
-            "achieved_GBps": gbs(ms_cold), "frac_of_hbm_peak": gbs(ms_cold) / HBM_PEAK_GBS,
-            "same_access_pattern_without_arithmetic_GBps": gbs(ms_probe),
-            "frac_of_that_ceiling": ms_probe / ms_cold,
-            "infinity_cache_resident_GBps": gbs(ms_warm),
+            "roofline": {"bound": "hbm", "bytes_moved_per_step": B_MOVED_F3_ZV, "achieved": moved(ms_cold), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": moved(ms_cold) / HBM_PEAK_GBS,
+                         "traffic": k1_traffic, "traffic_source": k1_src,
+                         "note": "priced on the 200 B that move (14 fields read, 11 written: the reference's inits leave the two end "
+                                 "velocities at zero and the kernel instantiated for that does not read them); on SURVEY 8d's "
+                                 "algorithmic 216 B the same launch is %.0f GB/s (%.3f of peak)" % (
+                                     B_ALG_F3 * count / (ms_cold * 1e-3) / 1e9, B_ALG_F3 * count / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS)},
+            "same_run_ceilings": {
+                "same_kernel_without_arithmetic_GBps": moved(ms_probe), "kernel_vs_that": ms_probe / ms_cold,
+                "device_copy_16B_per_lane_GBps": moved(ms_copy), "kernel_vs_copy": ms_copy / ms_cold,
+                "note": "k = 0 launch of the same kernel (14 loads + 11 stores per problem, nothing else) and a torch device copy of "
+                        "the same byte count, both cold, both timed in this run"},
+            "infinity_cache_resident_GBps": moved(ms_warm),
             "launches": len(spare)}
         # (b) configs[1]: 65,536 problems, exactly 50 steps each, one fused launch
         n2 = min(65536, count)
@@ -334,28 +378,50 @@ def main():
                                        "(about 35 of the 50 steps per problem run in the reference's post-convergence regime: "
                                        "~48 residual halvings per step)",
                            "ms": min(ms[1:]), "newton_steps_per_s": n2 * 50 / (min(ms[1:]) * 1e-3)}
-        # (c) configs[4]: F4, fp32, 1,048,576 problems x 50 steps (76 B algorithmic per step)
-        with rp.Batch(count, rp.VARIANT_F4, rp.DTYPE_F32, device=local_rank, stream=stream) as c5:
-            ms50, ms1 = [], []
-            for _ in range(3):
-                c5.set_problems_device(*ptrs)
-                c5.sync()
-                c5.event_record(4)
-                c5.step(50)
-                c5.event_record(5)
-                c5.sync()
-                ms50.append(c5.event_elapsed_ms(4, 5))
-            for _ in range(3):
-                c5.set_problems_device(*ptrs)
-                c5.sync()
-                c5.event_record(4)
-                c5.step(1)
-                c5.event_record(5)
-                c5.sync()
-                ms1.append(c5.event_elapsed_ms(4, 5))
-        line["f4_fp32"] = {"workload": "BASELINE configs[4] (C5): F4 onedpath2_ip, fp32, %d problems" % count,
-                           "fused_50_steps_ms": min(ms50), "newton_steps_per_s": count * 50 / (min(ms50) * 1e-3),
-                           "k1_launch_ms": min(ms1), "k1_achieved_GBps": 76.0 * count / (min(ms1) * 1e-3) / 1e9}
+        # (c) configs[4]: F4, 1,048,576 problems x 50 steps from the feasible start, fp32 state (76 B algorithmic per step), in
+        #     both arithmetic modes: fp32 state + fp64 arithmetic (per-problem parity bound, tests/test_gpu_parity.py) and
+        #     pure fp32 arithmetic (statistical bound only)
+        def f4_mode(dtype, tag, peak_tflops, flop_key):
+            with rp.Batch(count, rp.VARIANT_F4, dtype, device=local_rank, stream=stream) as c5:
+                ms50, ms1 = [], []
+                for _ in range(3):
+                    c5.set_problems_device(*ptrs)
+                    c5.sync()
+                    c5.event_record(4)
+                    c5.step(50)
+                    c5.event_record(5)
+                    c5.sync()
+                    ms50.append(c5.event_elapsed_ms(4, 5))
+                for _ in range(4):
+                    c5.set_problems_device(*ptrs)
+                    c5.sync()
+                    c5.event_record(4)
+                    c5.step(1)
+                    c5.event_record(5)
+                    c5.sync()
+                    ms1.append(c5.event_elapsed_ms(4, 5))
+            t50, t1 = min(ms50), min(ms1[1:])
+            flop, flop_src = profile_number(PROFILE_TAG + "_sq_counters.json", flop_key)
+            k1_traffic, k1_src = profile_number(PROFILE_TAG + "_hbm_traffic.json", "k_newton_stream16_f4_" + tag, "hbm_bytes_per_launch")
+            out = {"fused_50_steps_ms": t50, "newton_steps_per_s": count * 50 / (t50 * 1e-3),
+                   "k1_launch_ms": t1,
+                   "k1_roofline": {"bound": "hbm", "bytes_moved_per_step": B_MOVED_F4_F32_ZV, "achieved": B_MOVED_F4_F32_ZV * count / (t1 * 1e-3) / 1e9,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B_MOVED_F4_F32_ZV * count / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": k1_traffic, "traffic_source": k1_src,
+                                   "note": "68 B move per step (10 floats read, 7 written); SURVEY 8d's algorithmic 76 B gives %.0f GB/s" % (
+                                       B_ALG_F4_F32 * count / (t1 * 1e-3) / 1e9)}}
+            if flop is not None:
+                tf = flop * count * 50 / (t50 * 1e-3) / 1e12
+                out["fused_roofline"] = {"bound": "fp64_valu" if peak_tflops == FP64_PEAK_TFLOPS else "fp32_valu", "achieved": tf,
+                                         "peak": peak_tflops, "unit": "TFLOP/s", "frac": tf / peak_tflops,
+                                         "flop_per_newton_step": flop, "flop_per_newton_step_source": flop_src}
+            return out
+        line["f4_fp32"] = {"workload": "BASELINE configs[4] (C5): F4 onedpath2_ip, fp32 state, %d problems x 50 fused steps" % count,
+                           "fp32_state_fp64_arithmetic": f4_mode(rp.DTYPE_F32_STATE, "f32state", FP64_PEAK_TFLOPS, "_flop_per_f4_step_f32state"),
+                           "fp32_arithmetic": f4_mode(rp.DTYPE_F32, "f32", FP32_PEAK_TFLOPS, "_flop_per_f4_step_f32"),
+                           "note": "50 fused F4 steps from the feasible start spend most of their time in the line search (10-19 "
+                                   "feasibility halvings and up to 33 residual halvings per step from step ~6 on: F4 stalls, "
+                                   "README.md:34), which is why a fused step costs several times a k = 1 step"}
 
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(count, 1 << 19))

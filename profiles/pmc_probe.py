@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
-"""Tiny workload for PMC passes: 1M problems, 12 fused ungated steps, then one fused gated solve."""
-import os, sys
+"""Tiny workload for the SQ counter passes (rocprofv3 --pmc ... -- python3 profiles/pmc_probe.py).
+Every launch whose per-lane-step instruction counts are read from the counters is an ALL-LANES-ACTIVE launch of a
+known number of steps at 1 Mi problems:
+    F3 f64          12 fused ungated steps   -> k_solve_tiled<double, double, 3, false, ...>
+    F4 f32          12 fused ungated steps   -> k_solve_tiled<float, float, 4, false, ...>
+    F4 f32 state    12 fused ungated steps   -> k_solve_tiled<float, double, 4, false, ...>
+followed by the benchmark's gated solve (occupancy / busy counters of the real kernel) and one k = 1 launch."""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import rocket_path_amd as rp
+import rocket_path_amd as rp  # noqa: E402
+
 N = 1 << 20
+STEPS = 12
 p0, p1, p2 = rp.problems.generate(12345, 0, N, 0)
-b = rp.Batch(N)
-for _ in range(2):
+for variant, dtype in ((rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F32), (rp.VARIANT_F4, rp.DTYPE_F32_STATE)):
+    with rp.Batch(N, variant, dtype) as b:
+        for _ in range(2):
+            b.set_problems(p0, p1, p2)
+            b.step(STEPS)
+            b.sync()
+with rp.Batch(N) as b:
+    for _ in range(2):
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 200, 0)
+        b.sync()
     b.set_problems(p0, p1, p2)
-    b.step(12)
+    b.step(1)
     b.sync()
-for _ in range(2):
-    b.set_problems(p0, p1, p2)
-    b.solve(1e-8, 200, 0)
-    b.sync()
-b.set_problems(p0, p1, p2)
-b.solve(1e-8, 200, 1)     # host-polled: one gated launch per Newton step
-b.sync()

@@ -2,6 +2,9 @@
 """Fold rocprofv3 CSV output (gpurun_out/...) into the small summaries committed under profiles/.
 
     python profiles/summarize.py <tag> <kernel-stats dir> <FETCH_SIZE dir> <WRITE_SIZE dir> [<SQ dir> ...]
+
+kernel-stats / FETCH_SIZE / WRITE_SIZE come from passes over `python3 bench.py` (the driver's default command resp. a
+short run of it, see the _method strings); the SQ directories from passes over `python3 profiles/pmc_probe.py`.
 """
 import collections
 import csv
@@ -14,6 +17,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
 sq_dirs = sys.argv[5:]
+N = 1 << 20
+PROBE_STEPS = 12      # profiles/pmc_probe.py
 
 
 def one(d, pat):
@@ -37,9 +42,12 @@ def short(k):
 
 fetch, write = counters(fetch_dir), counters(write_dir)
 out = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --no-cpu-baseline "
-                  "--no-extras --steps 4 --warmup 1`; counters are KiB per dispatch (mean over dispatches); FETCH_SIZE is doubled "
-                  "as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B) -- calibrated here on "
-                  "k_reduce_partial, whose read volume is known exactly: (16 fields x 8 B + 4 B status) x 1,048,576 = 138,412,032 B"}
+                  "--steps 4 --warmup 1` (extras included: the k = 1 launches, the k = 0 probe, configs[1] and configs[4]); "
+                  "counters are KiB per dispatch, mean over the dispatches of a kernel; FETCH_SIZE is doubled as "
+                  "MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B).  Calibration in the same passes, "
+                  "on launches whose bytes are known exactly: k_reduce_partial reads (16 fields x 8 B + 4 B status) x 1,048,576 "
+                  "= 138,412,032 B (8 B per lane); the k = 0 launches of k_newton_stream16 read 14 and write 11 fields "
+                  "(16 B per lane): 117,440,512 + 92,274,688 B -- they are part of that kernel's mean"}
 for k in fetch:
     name = short(k)
     if not name.startswith("k_"):
@@ -48,12 +56,21 @@ for k in fetch:
     wr = write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
     out[name] = {"FETCH_SIZE_KiB": fetch[k].get("FETCH_SIZE"), "WRITE_SIZE_KiB": write.get(k, {}).get("WRITE_SIZE"),
                  "read_bytes_corrected": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
-gated = [k for k in out if k.startswith("k_solve_tiled<double, 3, true")]
-if gated:
-    out["k_solve_tiled_f3_f64"] = dict(out[gated[0]], kernel=gated[0],
-                                       expected="zero-end-velocity instantiation: (14x8 + 4 + 4 + 2) B read + (11x8 + 4 + 4) B written "
-                                                "per problem = 127.9 + 100.7 MB at n = 1,048,576")
-json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)       # read by bench.py
+
+
+def alias(key, prefix, expected):
+    hit = [k for k in out if k.startswith(prefix)]
+    if hit:
+        out[key] = dict(out[hit[0]], kernel=hit[0], expected=expected)
+
+
+alias("k_solve_tiled_f3_f64", "k_solve_tiled<double, double, 3, true",
+      "zero-end-velocity instantiation: (14x8 + 4 + 4 + 2) B read + (11x8 + 4 + 4) B written per problem = 127.9 + 100.7 MB at n = 1,048,576")
+alias("k_newton_stream16_f3_f64", "k_newton_stream16<double, double, 3, true", "14x8 B read + 11x8 B written per problem = 117.4 + 92.3 MB")
+alias("k_newton_stream16_f4_f32", "k_newton_stream16<float, float, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
+alias("k_newton_stream16_f4_f32state", "k_newton_stream16<float, double, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
+alias("k_solve_tiled_f4_f32", "k_solve_tiled<float, float, 4, false", "(10x4 + 2) B read + 7x4 B written per problem = 44.0 + 29.4 MB per 50-step launch")
+alias("k_solve_tiled_f4_f32state", "k_solve_tiled<float, double, 4, false", "(10x4 + 2) B read + 7x4 B written per problem = 44.0 + 29.4 MB per 50-step launch")
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag), "w"), indent=1)
 
 sq = {}
@@ -66,20 +83,32 @@ for name, c in sq.items():
     if "SQ_WAVES" in c and "SQ_INSTS_VALU" in c:
         c["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
         c["valu_busy_per_wave_cycle"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
-# flop per lane-step from the ungated 12-step launch of pmc_probe.py (1 Mi problems x 12 steps, every lane active):
+# flop per lane-step from the ungated 12-step launches of pmc_probe.py (1 Mi problems, every lane active):
 # SQ_INSTS_VALU_* count wave-instructions; x 64 lanes / (12 * 2^20 lane-steps)
-flop = None
+lane_steps = float(PROBE_STEPS) * N
+top = {}
 for name, c in sq.items():
-    if name.startswith("k_solve_tiled<double, 3, false") and "SQ_INSTS_VALU_FMA_F64" in c:
-        lane_steps = 12.0 * (1 << 20)
-        c["flop_per_lane_step"] = 64.0 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]
-                                          + c["SQ_INSTS_VALU_TRANS_F64"]) / lane_steps
-        c["valu_insts_per_wave_step"] = 64.0 * c["SQ_INSTS_VALU"] / lane_steps
-        flop = c["flop_per_lane_step"]
-if flop is not None:
-    sq["_flop_per_newton_step"] = flop
-json.dump({"_method": "rocprofv3 --pmc <SQ counters> -- python3 profiles/pmc_probe.py (1 Mi problems: 12 fused ungated steps, "
-                      "then one fused gated solve); SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles", **sq},
+    if not name.startswith("k_solve_tiled") or ", false, false, true>" not in name:
+        continue
+    f64 = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0)
+                  + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) / lane_steps
+    f32 = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F32", 0) + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_ADD_F32", 0)
+                  + c.get("SQ_INSTS_VALU_TRANS_F32", 0)) / lane_steps
+    c["flop_f64_per_lane_step"], c["flop_f32_per_lane_step"] = f64, f32
+    if "SQ_INSTS_VALU" in c:
+        c["valu_insts_per_lane_step"] = 64.0 * c["SQ_INSTS_VALU"] / lane_steps
+    if name.startswith("k_solve_tiled<double, double, 3"):
+        top["_flop_per_newton_step"] = f64
+    elif name.startswith("k_solve_tiled<float, float, 4"):
+        top["_flop_per_f4_step_f32"] = f32 + f64
+    elif name.startswith("k_solve_tiled<float, double, 4"):
+        top["_flop_per_f4_step_f32state"] = f64
+sq.update(top)
+json.dump({"_method": "rocprofv3 --pmc <SQ counters, <= 8 per pass> -- python3 profiles/pmc_probe.py (1 Mi problems: 12 fused ungated steps "
+                      "of F3 f64 / F4 f32 / F4 f32-state, then the fused gated F3 solve and one k = 1 launch); SQ_WAVE_CYCLES / "
+                      "SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles; flop = 2 FMA + MUL + ADD + TRANS wave-instructions x 64 lanes "
+                      "/ (12 x 2^20 lane-steps).  The F4 launches are the FIRST 12 steps from the feasible start (before F4's "
+                      "backtracking regime), so their flop per step undercounts the later steps of a 50-step run", **sq},
           open(os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag), "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k.startswith("k_solve") or k.startswith("k_newton")}, indent=1)[:1500])
-print(json.dumps(sq, indent=1)[:2500])
+print(json.dumps({k: v for k, v in out.items() if not k.startswith("k_") or "<" not in k}, indent=1)[:3000])
+print(json.dumps(top, indent=1))

@@ -135,12 +135,14 @@ template <typename T> struct Acc {
     T a[4];
     T gt[4];       // d a_j / d t_seg(j)   (not carried from step to step: rebuilt by accel_grads, see newton_step)
 };
-// What a lane carries from one step to the next: the reciprocals and the four accelerations.  The time
-// derivatives are rebuilt at the start of the step (14 flop): eight registers that are then free in the
-// residual backtracking loop, the register peak of the step.
-template <typename T> struct AccCarry {
+// What a lane carries from one step to the next: the reciprocals and the four accelerations.
+// GT = false: the time derivatives are rebuilt at the start of the step (14 flop) -- eight registers that are then free in
+// the residual backtracking loop, the register peak of the fixed-step kernels (memoisation state on top).  GT = true
+// (gated kernels, which have the registers): they are carried too.
+template <typename T, bool GT = false> struct AccCarry {
     T r0, r1;
     T a[4];
+    T gt[GT ? 4 : 1];
 };
 
 // d a_j / d vel1: dAdV1 of segment 0's ends (-2/t0, 4/t0), dAdV0 of segment 1's ends (-4/t1, 2/t1)
@@ -502,9 +504,11 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
 // (the reference recomputes the same numbers); what it buys is the reference's post-convergence regime, where x no
 // longer moves and every step still walks ~48 residual halvings (onedpath_ip.cpp:932-945) -- fixed-step runs.  A gated
 // solve stops long before that regime, so its kernels are built without the checks.
-template <typename T, int VARIANT, class P, bool MEMO = true>
+// PAIRED (with MEMO): the post-convergence residual loop evaluates two step lengths per trip; for the kernels that run
+// small batches (one wave per SIMD) and have the registers for it.
+template <typename T, int VARIANT, class P, bool MEMO = true, bool PAIRED = false>
 __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
-                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T> &c)
+                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO> &c)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     const T L = kp.limit;
@@ -517,8 +521,13 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         e.r0 = c.r0; e.r1 = c.r1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) e.a[j] = c.a[j];
-        accel_grads(k, v, e);
-        if constexpr (MEMO) feasible_here = all_satisfied<T, VARIANT>(e, L);
+        if constexpr (MEMO) {
+            accel_grads(k, v, e);
+            feasible_here = all_satisfied<T, VARIANT>(e, L);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e.gt[j] = c.gt[j];
+        }
         direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
         r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);      // onedpath_ip.cpp:932
     }
@@ -527,17 +536,25 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     // The smallest ratio is found on cross-multiplied pairs (lam_i / e_i < nb / eb  <=>  lam_i eb < nb e_i for
     // positive denominators; a non-negative dl_i gives e_i <= 0 and never wins, a NaN compares false and is skipped as
     // std::min skips it) and divided once, instead of eight divisions and a running minimum.
-    T s;
+    // Only a multiplier that the full step would drive negative (lam_i + dl_i < 0, i.e. ratio < 1) can bind, which on
+    // the benchmark distribution happens in steps 1-5 of a solve and for a quarter of the wave-steps: the arg-min runs
+    // behind that screen (a wave whose lanes all pass skips it).
+    T s = kp.boundary;
     {
-        T nb = T(1), eb = T(1);
+        T tmin = lam[0] + dl[0];
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const T ei = -dl[i];
-            const bool take = lam[i] * eb < nb * ei;
-            nb = take ? lam[i] : nb;
-            eb = take ? ei : eb;
+        for (int i = 1; i < NC; ++i) tmin = min_(tmin, lam[i] + dl[i]);
+        if (tmin < T(0)) {
+            T nb = T(1), eb = T(1);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const T ei = -dl[i];
+                const bool take = lam[i] * eb < nb * ei;
+                nb = take ? lam[i] : nb;
+                eb = take ? ei : eb;
+            }
+            s = min_(nb * rcp1_(eb), T(1)) * kp.boundary;
         }
-        s = (nb * rcp1_(eb)) * kp.boundary;
     }
 
     // -- backtrack until primal feasible (onedpath_ip.cpp:919-928) --
@@ -589,13 +606,35 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 #pragma unroll
             for (int j = 0; j < 4; ++j) et.a[j] = c.a[j];
             accel_grads(k, v, et);
-            for (; it < kp.max_bt; ++it) {
-                const T rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
-                if (rn <= r0n * (T(1) - kp.armijo * s)) {
-                    accepted = true;
-                    break;
+            if constexpr (PAIRED) {
+                // Two step lengths per trip, s and s/2, accepted in the reference's order.  A small fixed-step batch runs
+                // one wave per SIMD, where a single chain of dependent fp64 operations leaves the pipe idle most of the
+                // time: the second evaluation is independent work in the gaps (and half the loop overhead).
+                for (; it < kp.max_bt; it += 2) {
+                    const T s2 = s * kp.backtrack;
+                    const T rn1 = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
+                    const T rn2 = residual_norm<T, VARIANT, true>(et, lam, dl, s2, p, L);
+                    if (rn1 <= r0n * (T(1) - kp.armijo * s)) {
+                        accepted = true;
+                        break;
+                    }
+                    s = s2;
+                    if (it + 1 >= kp.max_bt) break;
+                    if (rn2 <= r0n * (T(1) - kp.armijo * s2)) {
+                        accepted = true;
+                        break;
+                    }
+                    s = s2 * kp.backtrack;
                 }
-                s *= kp.backtrack;
+            } else {
+                for (; it < kp.max_bt; ++it) {
+                    const T rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
+                    if (rn <= r0n * (T(1) - kp.armijo * s)) {
+                        accepted = true;
+                        break;
+                    }
+                    s *= kp.backtrack;
+                }
             }
         }
     }
@@ -607,10 +646,17 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 #pragma unroll
     for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
 
-    if (!accepted) accel_values(k, v, t0, t1, et);     // the loop ran out of halvings: its last s was never evaluated
+    if (!accepted) {                                   // the loop ran out of halvings: its last s was never evaluated
+        accel_values(k, v, t0, t1, et);
+        if constexpr (!MEMO) accel_grads(k, v, et);
+    }
     c.r0 = et.r0; c.r1 = et.r1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) c.a[j] = et.a[j];
+    if constexpr (!MEMO) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c.gt[j] = et.gt[j];
+    }
 }
 
 }  // namespace rp

@@ -10,7 +10,7 @@
 namespace rp {
 
 // Device-side view of one batch: `fields` SoA arrays of `n` elements, field f at
-// base + f * stride (stride >= n, multiple of 256 elements so every field is 1-2 KiB aligned).
+// base + f * stride (stride >= n, an odd multiple of 512 elements: 2-4 KiB aligned fields that do not alias in HBM, rp_batch.cpp).
 struct BatchView {
     void *base;            // double* or float*
     size_t stride;         // elements between consecutive fields

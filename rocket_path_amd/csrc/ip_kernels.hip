@@ -76,25 +76,32 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 // S = storage type of the batch.  When it differs from the compute type T (fp32 state, fp64 arithmetic) the state is
 // rounded to S after every step, so that a step is a function "S state -> S state" whatever the launch shape:
 // step(k) stays bit-identical to k x step(1).
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T>
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool PAIRED = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open)
 {
-    AccCarry<T> e;      // reciprocals + accelerations at the current point, carried from step to step
-    {
+    using Carry = AccCarry<T, GATED>;      // gated kernels carry the time derivatives as well (newton_step's MEMO = !GATED)
+    Carry e;            // the evaluation at the current point, carried from step to step
+    auto evaluate = [&]() {
         Acc<T> e0;
         accel_values(pr, v, t0, t1, e0);
         e.r0 = e0.r0; e.r1 = e0.r1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) e.a[j] = e0.a[j];
-    }
+        if constexpr (GATED) {
+            accel_grads(pr, v, e0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e.gt[j] = e0.gt[j];
+        }
+    };
+    evaluate();
 
     bool done = false;
     T best_gap = T(3.0e38);      // stall detector state (off unless kp.stall_window > 0)
     int since_best = 0;
     for (int s = 0; s < k; ++s) {
-        const T gap = duality_gap<T, VARIANT, AccCarry<T>>(e, lam, kp.limit);
+        const T gap = duality_gap<T, VARIANT, Carry>(e, lam, kp.limit);
         if (GATED) {
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
             if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; break; }
@@ -103,29 +110,25 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                 else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
             }
         }
-        newton_step<T, VARIANT, P, !GATED>(pr, kp, gap, v, t0, t1, lam, e);      // gated solves never reach the regime the memoisation is for
+        newton_step<T, VARIANT, P, !GATED, PAIRED>(pr, kp, gap, v, t0, t1, lam, e);      // gated solves never reach the regime the memoisation is for
         if constexpr (sizeof(S) != sizeof(T)) {
             v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
 #pragma unroll
             for (int c = 0; c < CMap<VARIANT>::NC; ++c) lam[c] = (T)(S)lam[c];
-            Acc<T> er;                       // the carried evaluation belongs to the unrounded point
-            accel_values(pr, v, t0, t1, er);
-            e.r0 = er.r0; e.r1 = er.r1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) e.a[j] = er.a[j];
+            evaluate();                      // the carried evaluation belongs to the unrounded point
         }
         ++it;
         ++steps_here;
     }
     if (GATED) {
         if (!done) {   // settle the status now so the host knows whether to launch again
-            const T gap = duality_gap<T, VARIANT, AccCarry<T>>(e, lam, kp.limit);
+            const T gap = duality_gap<T, VARIANT, Carry>(e, lam, kp.limit);
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; }
             else if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; }
         }
         st &= ~(RP_ST_NONFINITE | RP_ST_INFEASIBLE);
         if (!(finite_(v) && finite_(t0) && finite_(t1))) st |= RP_ST_NONFINITE;
-        if (!all_satisfied<T, VARIANT, AccCarry<T>>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
+        if (!all_satisfied<T, VARIANT, Carry>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
         still_open = !done;
     }
 }
@@ -240,7 +243,7 @@ k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, true>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
         S *f = base + i;
         f[0 * stride] = (S)v;
         f[1 * stride] = (S)t0;
@@ -251,6 +254,57 @@ k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
         cur = nxt;
         i = inext;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same streaming step with 16-byte accesses: a lane owns 16 / sizeof(S) CONSECUTIVE problems (two doubles, four
+// floats), loads each field of all of them with one global_load_dwordx4 (a wave moves 1 KiB per instruction), steps
+// them one after the other and stores each mutable field with one global_store_dwordx4.  No prefetch registers:
+// the 14 x 16 B a lane holds for its problems are the latency cover (57 KiB in flight per resident block).
+// Covers floor(n / (256 PER)) full blocks; launch_steps hands the ragged remainder to k_newton_stream.
+template <typename S> struct Vec16;
+template <> struct Vec16<double> { using type = double __attribute__((ext_vector_type(2))); static constexpr int PER = 2; };
+template <> struct Vec16<float> { using type = float __attribute__((ext_vector_type(4))); static constexpr int PER = 4; };
+
+template <typename S, typename T, int VARIANT, bool ZV>
+__global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
+k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    constexpr int CB = 3 + NC;
+    constexpr int NF = CB + 5;
+    constexpr int PER = Vec16<S>::PER;
+    using V = typename Vec16<S>::type;
+    const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * PER;
+    V f[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q)
+        if (!(ZV && (q == CB + 1 || q == CB + 4))) f[q] = *reinterpret_cast<const V *>(base + (size_t)q * stride + i);
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+        T v = (T)f[0][c], t0 = (T)f[1][c], t1 = (T)f[2][c];
+        T lam[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) lam[q] = (T)f[3 + q][c];
+        Prob<T, ZV> pr;
+        if constexpr (!ZV) {
+            pr.v0 = (T)f[CB + 1][c];
+            pr.v2 = (T)f[CB + 4][c];
+        }
+        pr.dx0 = (T)f[CB + 2][c] - (T)f[CB + 0][c];
+        pr.dx1 = (T)f[CB + 3][c] - (T)f[CB + 2][c];
+        int it = 0, steps_here = 0;
+        uint32_t st = 0;
+        bool still_open = false;
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        f[0][c] = (S)v;
+        f[1][c] = (S)t0;
+        f[2][c] = (S)t1;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) f[3 + q][c] = (S)lam[q];
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) *reinterpret_cast<V *>(base + (size_t)q * stride + i) = f[q];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -748,11 +802,24 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
                                              (const uint16_t *)b.order));
         return hipGetLastError();
     }
-    const unsigned cap = grid_env ? (unsigned)atoi(grid_env) : 512u;
-    unsigned grid = grid_for(b.n);
-    if (grid > cap) grid = cap;
-    RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton_stream<S, T, V, Z>), dim3(grid), dim3(kBlock), 0, stream,
-                                         (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
+    // k <= 2: memory-bound.  Full blocks of 256 lanes x 16 B go through k_newton_stream16; the ragged remainder (and,
+    // under RP_STREAM_SCALAR=1, everything: the A/B switch of the tuning log) through the 8-byte prefetching kernel.
+    static const bool scalar_only = getenv("RP_STREAM_SCALAR") != nullptr;
+    const size_t per_block = (size_t)kBlock * (16 / storage_size(b.dtype));
+    const size_t nfull = (scalar_only || grid_env || k > 2) ? 0 : b.n / per_block * per_block;      // k >= 3 on a small batch: one problem per lane fills more SIMDs
+    if (nfull > 0)
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton_stream16<S, T, V, Z>), dim3((unsigned)(nfull / per_block)), dim3(kBlock), 0, stream,
+                                             (S *)b.base, b.stride, k, make_kparams<T>(hp, V)));
+    if (nfull < b.n) {
+        BatchView w = b;
+        w.base = (char *)b.base + nfull * storage_size(b.dtype);
+        w.n = b.n - nfull;
+        const unsigned cap = grid_env ? (unsigned)atoi(grid_env) : 512u;
+        unsigned grid = grid_for(w.n);
+        if (grid > cap) grid = cap;
+        RP_DISPATCH_Z(w, hipLaunchKernelGGL((k_newton_stream<S, T, V, Z>), dim3(grid), dim3(kBlock), 0, stream,
+                                             (S *)w.base, w.stride, w.n, k, make_kparams<T>(hp, V)));
+    }
     return hipGetLastError();
 }
 

@@ -169,7 +169,13 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     b->view.n = n;
     b->view.variant = variant;
     b->view.dtype = dtype;
-    b->view.stride = (n + 255) / 256 * 256;
+    // Field f of problem i lives at base + f * stride + i.  A stride that is a large power of two in bytes (8 MiB at
+    // n = 2^20 doubles) puts element i of all 16 fields on the same HBM channel and bank: the 25 streams of a step then
+    // fight over one row buffer (measured, profiles/probes/stride_probe.py: 3.7 TB/s at k = 1 against 4.6 TB/s with the
+    // fields 1.25 KiB or more out of phase; plateau from there on).  So the stride is an ODD multiple of 512 elements.
+    b->view.stride = (n + 511) / 512 * 512;
+    if ((b->view.stride / 512) % 2 == 0) b->view.stride += 512;
+    if (const char *pad = getenv("RP_STRIDE_PAD")) b->view.stride += (size_t)atoi(pad) / 16 * 16;      // tuning probe only
     b->view.zero_end_vel = true;       // the state starts all-zero
     const size_t fields = (size_t)rp::state_len(variant);
 
