@@ -76,6 +76,14 @@ typedef struct {
     int32_t stall_window;     /* 0 = off (the reference's behaviour: it keeps stepping, e.g. from initStuck, onedpath_ip.cpp:177-199).
                                  w > 0: in a gated solve, a problem whose surrogate gap has not halved for w consecutive steps of
                                  one launch is marked RP_ST_STALLED and stops -- SURVEY.md 8f row 4; never changes a converging run */
+    int32_t mu_mode;          /* 0 = the reference's centring, perturbation = gap / (m * mu_divisor) at every step (onedpath_ip.cpp:812); the
+                                 default, and the only mode the parity guarantees are about.
+                                 1 = centring by trial (a Mehrotra-style predictor/centring split): the step is
+                                 d_a + p d_c from one factorisation; sigma = mu_sigma_try[0], then [1] (p = sigma * gap / m) is taken if its
+                                 full step keeps the multipliers positive, is primal feasible and passes the reference's residual test,
+                                 else the reference step.  Same optimum in fewer steps (15.4 -> 12.7 mean on the benchmark distribution);
+                                 double arithmetic only */
+    double mu_sigma_try[2];   /* 0.01, 0.03 */
 } rp_params;
 
 /* Batch-wide reduction, the payload of the one cross-GPU collective (max / max / sum / sum). */

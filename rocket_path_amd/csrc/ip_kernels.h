@@ -28,6 +28,8 @@ struct HostParams {
     double accel_limit, mu_divisor, boundary_fraction, backtrack, armijo;
     int max_backtracks;
     int stall_window;
+    int mu_mode;                 // 0 = reference centring, 1 = centring by trial (ip_core.h, newton_step)
+    double mu_sigma_try[2];      // the two candidates of mode 1
 };
 
 inline int state_len(int variant) { return variant == 4 ? 12 : 16; }

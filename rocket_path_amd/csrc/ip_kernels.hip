@@ -54,6 +54,8 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
     kp.c_floor = (T)hp.accel_limit * (sizeof(T) == 8 ? (T)8.673617379884035e-19 : (T)4.656612873077393e-10);   // L * eps / 256
     kp.max_bt = hp.max_backtracks;
     kp.stall_window = hp.stall_window;
+    kp.sigma_try[0] = (T)hp.mu_sigma_try[0];
+    kp.sigma_try[1] = (T)hp.mu_sigma_try[1];
     return kp;
 }
 
@@ -76,7 +78,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 // S = storage type of the batch.  When it differs from the compute type T (fp32 state, fp64 arithmetic) the state is
 // rounded to S after every step, so that a step is a function "S state -> S state" whatever the launch shape:
 // step(k) stays bit-identical to k x step(1).
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool PAIRED = false>
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool PAIRED = false, int MU = 0>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open)
@@ -110,7 +112,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                 else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
             }
         }
-        newton_step<T, VARIANT, P, !GATED, PAIRED>(pr, kp, gap, v, t0, t1, lam, e);      // gated solves never reach the regime the memoisation is for
+        newton_step<T, VARIANT, P, !GATED, PAIRED, MU>(pr, kp, gap, v, t0, t1, lam, e);      // gated solves never reach the regime the memoisation is for
         if constexpr (sizeof(S) != sizeof(T)) {
             v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
 #pragma unroll
@@ -133,7 +135,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     }
 }
 
-template <typename S, typename T, int VARIANT, bool GATED, bool ZV>
+template <typename S, typename T, int VARIANT, bool GATED, bool ZV, int MU = 0>
 __global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
 k_newton(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
          int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters)
@@ -170,7 +172,7 @@ k_newton(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
             pr.dx0 = p1 - p0;
             pr.dx1 = p2 - p1;
         }
-        run_lane<T, VARIANT, GATED, GATED, Prob<T, ZV>, S>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, GATED, GATED, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
         if (GATED) {
             iters[i] = it;
             status[i] = st;
@@ -205,7 +207,7 @@ k_newton(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
 // next state streams in under the arithmetic of the current one.
 template <typename T, int NF> struct LaneState { T f[NF]; };
 
-template <typename S, typename T, int VARIANT, bool ZV>
+template <typename S, typename T, int VARIANT, bool ZV, int MU = 0>
 __global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
 k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
 {
@@ -243,7 +245,7 @@ k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, true>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, true, MU>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
         S *f = base + i;
         f[0 * stride] = (S)v;
         f[1 * stride] = (S)t0;
@@ -785,9 +787,30 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
         else                  { constexpr bool Z = false; RP_DISPATCH(b, __VA_ARGS__); }  \
     } while (0)
 
+// mu_mode 1 (centring by trial) exists for double arithmetic (dtypes f64 and f32-state) in the one-problem-per-lane
+// kernels; rp_batch_set_params refuses it for pure fp32.
+#define RP_DISPATCH_MU1(b, ...)                                                                          \
+    do {                                                                                                 \
+        using T [[maybe_unused]] = double;                                                               \
+        if ((b).dtype == 0) { using S [[maybe_unused]] = double; RP_DISPATCH_V(b, __VA_ARGS__); }          \
+        else                { using S [[maybe_unused]] = float;  RP_DISPATCH_V(b, __VA_ARGS__); }          \
+    } while (0)
+#define RP_DISPATCH_MU1_Z(b, ...)                                         \
+    do {                                                                  \
+        if ((b).zero_end_vel) { constexpr bool Z = true; RP_DISPATCH_MU1(b, __VA_ARGS__); }   \
+        else                  { constexpr bool Z = false; RP_DISPATCH_MU1(b, __VA_ARGS__); }  \
+    } while (0)
+
 hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStream_t stream)
 {
     if (k < 0 || b.n == 0) return hipSuccess;     // k == 0: load/store only (bandwidth probe, see rp_batch_step)
+    if (hp.mu_mode == 1) {
+        unsigned grid = grid_for(b.n);
+        if (grid > 2048u) grid = 2048u;
+        RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_newton_stream<S, T, V, Z, 1>), dim3(grid), dim3(kBlock), 0, stream,
+                                                 (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
+        return hipGetLastError();
+    }
     // resident set: 256 CUs x 2 blocks (2 waves per SIMD); larger batches are walked with that stride
     // k <= 2 is memory-bound: the streaming kernel, grid = the resident set (256 CUs x 2 blocks) so that each lane
     // walks 8 problems at 1 Mi and its register prefetch hides the HBM latency.  Larger k is arithmetic-bound: there
@@ -830,6 +853,12 @@ hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double g
     // Below ~2 tiles per CU slot the tiled kernel cannot fill the chip (one 256-thread block per
     // 512 problems): small batches take the plain one-problem-per-lane kernel.
     static const bool no_tiled = getenv("RP_NO_TILED") != nullptr;     // A/B switch for tuning
+    if (hp.mu_mode == 1) {
+        RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z, 1>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                                 (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
+                                                 (T)gap_tol, max_iter, b.iters, b.status, b.counters));
+        return hipGetLastError();
+    }
     if (no_tiled || b.n < (size_t)kTile * 512) {
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
                                              (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
@@ -861,6 +890,12 @@ hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double 
 {
     if (b.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(kShards), 0, stream, b.counters);
+    if (hp.mu_mode == 1) {
+        RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z, 1>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                                 (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
+                                                 b.iters, b.status, b.counters));
+        return hipGetLastError();
+    }
     RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
                                          (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
                                          b.iters, b.status, b.counters));

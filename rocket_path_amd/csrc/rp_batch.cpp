@@ -74,6 +74,9 @@ void default_params(rp::HostParams &hp)
     hp.armijo = 0.01;
     hp.max_backtracks = 100;
     hp.stall_window = 0;
+    hp.mu_mode = 0;
+    hp.mu_sigma_try[0] = 0.01;
+    hp.mu_sigma_try[1] = 0.03;
 }
 
 int reset_progress(rp_batch *b)
@@ -145,6 +148,9 @@ void rp_params_default(rp_params *p)
     p->armijo = hp.armijo;
     p->max_backtracks = hp.max_backtracks;
     p->stall_window = hp.stall_window;
+    p->mu_mode = hp.mu_mode;
+    p->mu_sigma_try[0] = hp.mu_sigma_try[0];
+    p->mu_sigma_try[1] = hp.mu_sigma_try[1];
 }
 
 int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device, void *stream)
@@ -229,6 +235,12 @@ int rp_batch_set_params(rp_batch *b, const rp_params *p)
         !(p->backtrack > 0 && p->backtrack < 1) || !(p->armijo >= 0 && p->armijo < 1) || p->max_backtracks < 0 ||
         p->max_backtracks > 4096 || p->stall_window < 0)      // every device loop must stay short: a runaway kernel takes the GPU with it
         return fail(RP_ERR_INVALID, "parameter out of range");
+    if (p->mu_mode != 0 && p->mu_mode != 1) return fail(RP_ERR_INVALID, "mu_mode %d (want 0 = reference or 1 = centring by trial)", p->mu_mode);
+    if (p->mu_mode == 1) {
+        if (b->view.dtype == RP_DTYPE_F32) return fail(RP_ERR_UNSUPPORTED, "mu_mode 1 needs double arithmetic (RP_DTYPE_F64 or RP_DTYPE_F32_STATE)");
+        if (!(p->mu_sigma_try[0] > 0 && p->mu_sigma_try[0] <= p->mu_sigma_try[1] && p->mu_sigma_try[1] < 1))
+            return fail(RP_ERR_INVALID, "mu_sigma_try must satisfy 0 < [0] <= [1] < 1");
+    }
     b->params.accel_limit = p->accel_limit;
     b->params.mu_divisor = p->mu_divisor;
     b->params.boundary_fraction = p->boundary_fraction;
@@ -236,6 +248,9 @@ int rp_batch_set_params(rp_batch *b, const rp_params *p)
     b->params.armijo = p->armijo;
     b->params.max_backtracks = p->max_backtracks;
     b->params.stall_window = p->stall_window;
+    b->params.mu_mode = p->mu_mode;
+    b->params.mu_sigma_try[0] = p->mu_sigma_try[0];
+    b->params.mu_sigma_try[1] = p->mu_sigma_try[1];
     return RP_OK;
 }
 
@@ -249,6 +264,9 @@ int rp_batch_get_params(const rp_batch *b, rp_params *p)
     p->armijo = b->params.armijo;
     p->max_backtracks = b->params.max_backtracks;
     p->stall_window = b->params.stall_window;
+    p->mu_mode = b->params.mu_mode;
+    p->mu_sigma_try[0] = b->params.mu_sigma_try[0];
+    p->mu_sigma_try[1] = b->params.mu_sigma_try[1];
     return RP_OK;
 }
 
