@@ -64,6 +64,8 @@ typedef enum {
 #define RP_ST_NONFINITE 4u  /* a variable became NaN/inf */
 #define RP_ST_INFEASIBLE 8u /* some c_i > 0 at the last gate check (constraintsSatisfied false) */
 #define RP_ST_STALLED 16u   /* stall detector fired (only when rp_params.stall_window > 0); the problem is left alone from then on */
+#define RP_ST_WRONG_WAY 32u /* with the stall detector on: a gated launch left the problem unconverged with a total duration no smaller than
+                               the one it started the launch with -- F4's "settles the wrong direction" (README.md:34) */
 
 /* Solver constants, defaults = the reference's compile-time values. */
 typedef struct {

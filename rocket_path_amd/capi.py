@@ -14,7 +14,7 @@ RP_OK = 0
 RP_ERR_INVALID, RP_ERR_DEVICE, RP_ERR_NOMEM, RP_ERR_UNSUPPORTED, RP_ERR_NO_DEVICE = 1, 2, 3, 4, 5
 VARIANT_F3, VARIANT_F4 = 3, 4
 DTYPE_F64, DTYPE_F32, DTYPE_F32_STATE = 0, 1, 2      # 2: fp32 state in HBM, fp64 arithmetic (include/rp_batch.h)
-ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_INFEASIBLE, ST_STALLED = 1, 2, 4, 8, 16
+ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_INFEASIBLE, ST_STALLED, ST_WRONG_WAY = 1, 2, 4, 8, 16, 32
 
 
 class RpError(RuntimeError):

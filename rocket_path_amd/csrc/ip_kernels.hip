@@ -102,6 +102,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     bool done = false;
     T best_gap = T(3.0e38);      // stall detector state (off unless kp.stall_window > 0)
     int since_best = 0;
+    const T objective_in = t0 + t1;      // the objective (total duration) this launch started from: RP_ST_WRONG_WAY below
     for (int s = 0; s < k; ++s) {
         const T gap = duality_gap<T, VARIANT, Carry>(e, lam, kp.limit);
         if (GATED) {
@@ -129,6 +130,10 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
             else if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; }
         }
         st &= ~(RP_ST_NONFINITE | RP_ST_INFEASIBLE);
+        // F4 "tends to settle the wrong direction" (README.md:34): from the feasible start its total duration GROWS (7.0 ->
+        // 7.07 on the default problem, optimum 4.0) while the gap sticks near 0.47.  With the stall detector on, a problem that
+        // stops unconverged with an objective no better than the one this launch started from is flagged.
+        if (STALL && kp.stall_window > 0 && steps_here > 0 && !(st & RP_ST_CONVERGED) && !(t0 + t1 < objective_in)) st |= RP_ST_WRONG_WAY;
         if (!(finite_(v) && finite_(t0) && finite_(t1))) st |= RP_ST_NONFINITE;
         if (!all_satisfied<T, VARIANT, Carry>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
         still_open = !done;

@@ -652,3 +652,93 @@ def test_tiled_ungated_steps_equal_streamed_single_steps_bitwise():
         assert np.array_equal(a.get_state(), b.get_state())
         it, _ = a.get_iters()
         assert np.all(it == 5)
+
+
+# ---------------------------------------------------------------- mu schedule option, F4 settling flag
+def test_mu_mode_defaults_to_the_reference_and_is_validated(g3):
+    n = 2048
+    with rp.Batch(n) as b:
+        p = b.get_params()
+        assert p.mu_mode == 0 and (p.mu_sigma_try[0], p.mu_sigma_try[1]) == (0.01, 0.03)
+        with pytest.raises(rp.RpError):
+            b.set_params(mu_mode=2)
+        b.set_params(mu_mode=1)
+        b.set_state(g3["init"][:n])
+        b.solve(1e-8, 200, 0)
+        b.set_params(mu_mode=0)              # back to the reference: bit-identical to the golden run
+        b.set_state(g3["init"][:n])
+        b.solve(1e-8, 200, 0)
+        it, status = b.get_iters()
+        assert np.array_equal(it, g3["iters"][:n]) and serr(b.get_state()[:, :3], g3["gated"][:n, :3]) < TOL
+    with rp.Batch(8, rp.VARIANT_F4, rp.DTYPE_F32) as c:
+        with pytest.raises(rp.RpError):
+            c.set_params(mu_mode=1)          # centring by trial needs double arithmetic
+
+
+@pytest.mark.parametrize("steps_per_launch", [0, 6])
+def test_mu_mode_1_reaches_the_same_optimum_in_fewer_steps(steps_per_launch):
+    n = 20000
+    p0, p1, p2 = rp.problems.generate(2468, 0, n, rp.problems.DIST_MONOTONE)      # the C3 distribution
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0, p1, p2)
+        b.set_params(mu_mode=1)
+        a.solve(1e-8, 200, steps_per_launch)
+        b.solve(1e-8, 200, steps_per_launch)
+        ia, sa = a.get_iters()
+        ib, sb = b.get_iters()
+        xa, xb = a.get_state(), b.get_state()
+        gb = b.reduce()["max_gap"]
+    assert np.all(sa == rp.ST_CONVERGED) and np.all(sb == rp.ST_CONVERGED) and gb < 1e-8
+    print("mean steps: reference %.2f, centring by trial %.2f (max %d / %d)" % (ia.mean(), ib.mean(), ia.max(), ib.max()))
+    assert ib.mean() < 0.9 * ia.mean() and ib.max() <= ia.max()
+    assert serr(xb[:, :3], xa[:, :3]) < 1e-8          # both stop at a gap below 1e-8: same optimum to that accuracy
+
+
+def test_mu_mode_1_ungated_steps_and_the_stuck_state():
+    n = 4096
+    p0, p1, p2 = rp.problems.generate(97, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0, p1, p2)
+        b.set_params(mu_mode=1)
+        a.step(10)
+        b.step(10)
+        _, acc = b.sample()
+        assert np.all(np.isfinite(b.get_state())) and np.max(np.abs(acc)) <= 100.0      # the trial steps keep feasibility too
+        a.solve(1e-8, 200, 0)
+        b.solve(1e-8, 200, 0)                    # ungated steps and the gated solve mix freely
+        assert np.all(b.get_iters()[1] == rp.ST_CONVERGED) and b.get_iters()[0].mean() < a.get_iters()[0].mean()
+        assert serr(b.get_state()[:, :3], a.get_state()[:, :3]) < 1e-8
+        # initStuck (onedpath_ip.cpp:177-199): converges or is flagged, never spins silently
+        b.set_params(mu_mode=1, stall_window=8)
+        b.init_stuck()
+        b.solve(1e-8, 200, 0)
+        it, st = b.get_iters()
+        assert np.all((st & rp.ST_CONVERGED) | (st & rp.ST_STALLED)) and np.all(it < 200)
+
+
+def test_f4_wrong_way_settling_is_flagged_with_the_stall_detector_on():
+    # F4 never converges from the feasible start: its duration sum grows while the gap sticks (README.md:34)
+    n = 1024
+    p0, p1, p2 = rp.problems.generate(12345, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n, rp.VARIANT_F4) as b:
+        b.set_problems(p0, p1, p2)
+        t_in = b.get_state()[:, 1:3].sum(axis=1)
+        b.solve(1e-6, 60, 0)
+        _, st = b.get_iters()
+        assert not np.any(st & rp.ST_WRONG_WAY) and np.all(st & rp.ST_MAXITER)      # detector off: the reference's behaviour
+        b.set_params(stall_window=8)
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-6, 200, 0)
+        it, st = b.get_iters()
+        t_out = b.get_state()[:, 1:3].sum(axis=1)
+    assert np.all(st & rp.ST_STALLED) and not np.any(st & rp.ST_CONVERGED) and np.all(it < 60)
+    wrong = (st & rp.ST_WRONG_WAY) != 0
+    assert np.array_equal(wrong, ~(t_out < t_in)) and wrong.mean() > 0.5
+    with rp.Batch(n) as c:                                     # F3 on the same problems converges and is never flagged
+        c.set_params(stall_window=8)
+        c.set_problems(p0, p1, p2)
+        c.solve(1e-8, 200, 0)
+        _, st3 = c.get_iters()
+    assert np.all(st3 == rp.ST_CONVERGED)
