@@ -121,6 +121,9 @@ RP_API int rp_batch_init_stuck(rp_batch *b);   /* initStuck, onedpath_ip.cpp:177
 RP_API int rp_batch_set_problems(rp_batch *b, const double *pos0, const double *pos1, const double *pos2);
 /* Same with device-resident inputs (no PCIe in the path). */
 RP_API int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double *d_pos1, const double *d_pos2);
+/* Back to the feasible start of the positions the batch already holds (the `I` key for per-problem positions): nothing
+ * crosses the boundary.  Asynchronous. */
+RP_API int rp_batch_restart(rp_batch *b);
 /* Whole state in the reference's AoS layout, n * 16 (F3) or n * 12 (F4) doubles.  Synchronous. */
 RP_API int rp_batch_set_state(rp_batch *b, const double *aos);
 RP_API int rp_batch_get_state(rp_batch *b, double *aos);

@@ -81,6 +81,10 @@ class Batch:
         """Device pointers (ints) to n float64 each, e.g. torch tensors' data_ptr()."""
         capi.check(self._lib.rp_batch_set_problems_device(self._h, *[ctypes.c_void_p(p) for p in (d_pos0, d_pos1, d_pos2)]))
 
+    def restart(self):
+        """Feasible start again from the positions already in the batch (no input crosses the boundary)."""
+        capi.check(self._lib.rp_batch_restart(self._h))
+
     def set_state(self, aos):
         a = np.ascontiguousarray(aos, dtype=np.float64)
         if a.shape != (self.n, self.state_len):

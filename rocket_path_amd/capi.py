@@ -55,6 +55,7 @@ SIGNATURES = {
     "rp_batch_init_stuck": (ctypes.c_int, [_vp]),
     "rp_batch_set_problems": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "rp_batch_set_problems_device": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "rp_batch_restart": (ctypes.c_int, [_vp]),
     "rp_batch_set_state": (ctypes.c_int, [_vp, _vp]),
     "rp_batch_get_state": (ctypes.c_int, [_vp, _vp]),
     "rp_batch_get_state_range": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _vp]),

@@ -6,6 +6,11 @@
 // problems; F1/F2 (fixptpath, onedpath) are out of scope and left empty.
 //
 //   rp_headless [--n N] [--seed S] [--f4] [--f32] [--gpus G] [--watch I] [--keys "i n n s"] [--solve]
+//   rp_headless --gpus G --n N --seed S --bench K [--warmup W]
+//
+// --bench K (with --gpus G): the single-process multi-GPU path timed like bench.py times the one-process-per-GPU path --
+// W untimed then K timed passes (restart + fused gated solve of every shard, gap < 1e-8, cap 200) plus the one RCCL
+// summary all-reduce -- and ONE JSON line with bench.py's keys, per-device HIP-event times included.
 //
 // Redisplay works as under GLUT: a handled key makes the problem call repaint() (here: the hook below marks the
 // window dirty, as glutPostRedisplay does, rocket_path.cpp:178-182), and the shell then calls onDraw() on the current
@@ -52,6 +57,7 @@ int main(int argc, char **argv)
     int gpus = 0;
     size_t watch = 0;
     unsigned redraws = 0;
+    int benchPasses = 0, benchWarmup = 3;
     std::string keys = "s";
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--n") && i + 1 < argc) n = (size_t)strtoull(argv[++i], nullptr, 10);
@@ -62,6 +68,8 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--f4")) startF4 = true;
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--watch") && i + 1 < argc) watch = (size_t)strtoull(argv[++i], nullptr, 10);
+        else if (!strcmp(argv[i], "--bench") && i + 1 < argc) benchPasses = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) benchWarmup = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     if (n == 0) { fprintf(stderr, "--n must be positive\n"); return 2; }
@@ -78,6 +86,25 @@ int main(int argc, char **argv)
                 p2[i] = p1[i] + 10.0 + 500.0 * u01(seed, 3 * i + 3);
             }
             sharded.setProblems(p0.data(), p1.data(), p2.data());
+        }
+        if (benchPasses > 0) {
+            if (!haveSeed) { fprintf(stderr, "--bench needs --seed (per-problem positions)\n"); return 2; }
+            ShardedOneDPathIP::BenchResult br;
+            if (!sharded.bench(benchPasses, benchWarmup, 1e-8, 200, br)) return 1;
+            const double perGpu = (double)n / gpus;
+            printf("{\"metric\": \"interior-point Newton steps/sec (whole node) + achieved HBM GB/s, 1M-problem batch\", \"value\": %.6g, "
+                   "\"unit\": \"Newton steps/s\", \"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.6g, "
+                   "\"higher_is_better\": true, \"scaling\": \"weak\", \"vs_baseline\": null, \"dtype\": \"%s\", \"data\": \"synthetic\", "
+                   "\"config\": {\"workload\": \"single-process host (ShardedOneDPathIP): %.0f F3 problems per GPU, convergence-gated (gap < 1e-8, cap 200), "
+                   "monotone seeded positions, feasible-start rule, one fused launch per shard per pass; each pass restarts its shard on the device\", "
+                   "\"problems_total\": %zu, \"newton_steps_per_pass\": %.0f, \"converged\": %.0f, \"max_gap\": %.6g, \"max_residual_sq\": %.6g, "
+                   "\"sharding\": \"contiguous shards, no data-path collective; one grouped 32-byte RCCL all-reduce (ncclCommInitAll)\"}, "
+                   "\"per_device_ms_per_pass\": [",
+                   br.stepsTotal / br.seconds, gpus, benchPasses, benchWarmup, br.msPerPass, f32 ? "f32" : "f64", perGpu, n,
+                   br.stepsTotal / benchPasses, br.converged, br.maxGap, br.maxResidualSq);
+            for (size_t d = 0; d < br.deviceMs.size(); ++d) printf("%s%.6g", d ? ", " : "", br.deviceMs[d]);
+            printf("]}\n");
+            return 0;
         }
         sharded.onActivate();
         if (solve) sharded.solve();

@@ -1,6 +1,7 @@
 // sharded_problem.cpp -- see sharded_problem.h.
 #include "sharded_problem.h"
 
+#include <chrono>
 #include <cstdio>
 
 #include <rccl/rccl.h>
@@ -135,6 +136,49 @@ void ShardedOneDPathIP::solve(double gapTol, int maxIter)
     if (!ok_) return;
     for (rp_batch *b : shards_) check(rp_batch_solve(b, gapTol, maxIter, 0), "rp_batch_solve");
     syncAll();
+}
+
+void ShardedOneDPathIP::restart()
+{
+    if (!ok_) return;
+    for (rp_batch *b : shards_) check(rp_batch_restart(b), "rp_batch_restart");
+}
+
+bool ShardedOneDPathIP::bench(int passes, int warmup, double gapTol, int maxIter, BenchResult &out)
+{
+    if (!ok_ || passes < 1 || warmup < 0) return false;
+    rp_reduction r;
+    for (int w = 0; w < warmup; ++w) {
+        restart();
+        for (rp_batch *b : shards_) check(rp_batch_solve(b, gapTol, maxIter, 0), "rp_batch_solve");
+    }
+    if (!reduce(r)) return false;                 // communicator and summary path warmed up outside the timed region
+    syncAll();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (rp_batch *b : shards_) check(rp_batch_event_record(b, 0), "rp_batch_event_record");
+    for (int k = 0; k < passes; ++k) {            // every device gets its whole queue before any is waited for
+        for (rp_batch *b : shards_) {
+            check(rp_batch_restart(b), "rp_batch_restart");
+            check(rp_batch_solve(b, gapTol, maxIter, 0), "rp_batch_solve");
+        }
+    }
+    for (rp_batch *b : shards_) check(rp_batch_event_record(b, 1), "rp_batch_event_record");
+    const bool good = reduce(r);                  // the one collective: reduction kernels + the grouped 32-byte all-reduce + read-back
+    syncAll();
+    out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    out.msPerPass = out.seconds * 1e3 / passes;
+    out.deviceMs.clear();
+    for (rp_batch *b : shards_) {
+        float ms = 0.f;
+        check(rp_batch_event_elapsed_ms(b, 0, 1, &ms), "rp_batch_event_elapsed_ms");
+        out.deviceMs.push_back(ms / passes);
+    }
+    // every pass solves the same problems from the same start: steps of the last pass (what the summary counts) x passes
+    out.stepsTotal = r.total_steps * passes;
+    out.converged = r.n_converged;
+    out.maxGap = r.max_gap;
+    out.maxResidualSq = r.max_residual_sq;
+    return good;
 }
 
 bool ShardedOneDPathIP::reduce(rp_reduction &out)

@@ -35,6 +35,11 @@ struct ShardedOneDPathIP : public Problem {
     void step(int k);
     void solve(double gapTol = 1e-8, int maxIter = 200);
     bool reduce(rp_reduction &out);               // the all-reduced summary (identical on every device)
+    void restart();                               // feasible start again from the positions the shards hold (device side only)
+    // K timed passes (restart + fused gated solve on every shard) after W untimed ones, then ONE all-reduced summary; per-device
+    // times come from HIP events on each shard's stream, the job's time is the slowest device's.  Fills the numbers bench.py prints.
+    struct BenchResult { double seconds, msPerPass, stepsTotal, converged, maxGap, maxResidualSq; std::vector<double> deviceMs; };
+    bool bench(int passes, int warmup, double gapTol, int maxIter, BenchResult &out);
     bool readState(std::vector<double> &aos);     // concatenation of the shards, problem order
 
 private:

@@ -51,6 +51,7 @@ hipError_t launch_aos_to_soa(const BatchView &b, const double *d_aos, hipStream_
 hipError_t launch_soa_to_aos(const BatchView &b, double *d_aos, hipStream_t stream);
 hipError_t launch_init_feasible(const BatchView &b, const HostParams &hp, const double *d_pos0, const double *d_pos1,
                                 const double *d_pos2, hipStream_t stream);
+hipError_t launch_restart_feasible(const BatchView &b, const HostParams &hp, hipStream_t stream);      // same rule, positions already in the batch
 hipError_t launch_init_const(const BatchView &b, const double *host_state /* state_len values */, hipStream_t stream);
 hipError_t launch_nudge(const BatchView &b, int field, double delta, hipStream_t stream);
 hipError_t launch_clear_progress(const BatchView &b, hipStream_t stream);

@@ -609,6 +609,28 @@ k_init_feasible(T *__restrict__ base, size_t stride, size_t n, double limit, con
     f[(CB + 4) * stride] = T(0);
 }
 
+// The same start rule applied to the positions the batch already holds (its own constant fields): restart without
+// any input crossing the boundary again.
+template <typename S, int VARIANT>
+__global__ void __launch_bounds__(kBlock)
+k_restart_feasible(S *__restrict__ base, size_t stride, size_t n, double limit)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    constexpr int CB = 3 + NC;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    S *f = base + i;
+    const double p0 = (double)f[(CB + 0) * stride], p1 = (double)f[(CB + 2) * stride], p2 = (double)f[(CB + 3) * stride];
+    const double scale = 3.5 / __builtin_sqrt(12.0);
+    f[0 * stride] = S(0);
+    f[1 * stride] = (S)(scale * __builtin_sqrt(6.0 * __builtin_fabs(p1 - p0) / limit));
+    f[2 * stride] = (S)(scale * __builtin_sqrt(6.0 * __builtin_fabs(p2 - p1) / limit));
+#pragma unroll
+    for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = S(1);
+    f[(CB + 1) * stride] = S(0);
+    f[(CB + 4) * stride] = S(0);
+}
+
 // Every problem gets the same state (initDefault / initStuck broadcast).
 struct ConstState { double v[16]; };
 
@@ -949,6 +971,13 @@ hipError_t launch_init_feasible(const BatchView &b, const HostParams &hp, const 
 {
     RP_DISPATCH(b, hipLaunchKernelGGL((k_init_feasible<S, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
                                        (S *)b.base, b.stride, b.n, hp.accel_limit, d_pos0, d_pos1, d_pos2));
+    return hipGetLastError();
+}
+
+hipError_t launch_restart_feasible(const BatchView &b, const HostParams &hp, hipStream_t stream)
+{
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_restart_feasible<S, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                       (S *)b.base, b.stride, b.n, hp.accel_limit));
     return hipGetLastError();
 }
 

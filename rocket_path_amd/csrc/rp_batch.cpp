@@ -323,6 +323,16 @@ int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double
     return reset_progress(b);
 }
 
+int rp_batch_restart(rp_batch *b)
+{
+    RP_NEED(b);
+    RP_HIP(rp::launch_restart_feasible(b->view, b->params, b->stream));
+    b->view.zero_end_vel = true;
+    b->ungated_steps = 0.0;
+    RP_HIP(rp::launch_clear_progress(b->view, b->stream));      // the positions have not changed: the scheduling order stays valid
+    return RP_OK;
+}
+
 int rp_batch_set_problems(rp_batch *b, const double *pos0, const double *pos1, const double *pos2)
 {
     RP_NEED(b);

@@ -156,3 +156,43 @@ def test_field_ptr_to_an_end_velocity_selects_the_general_kernels(oracle):
     zero[:, 15] = 0.0
     oracle.batch_steps(3, zero, 5)
     assert serr(out[sl, :3], zero[:, :3]) > 1e-6      # the velocities matter: the ZV instantiation would have given this
+
+
+def test_restart_is_the_feasible_start_of_the_positions_in_the_batch():
+    n = 512 * 512 + 17
+    p0, p1, p2 = rp.problems.generate(5150, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0, p1, p2)
+        init = a.get_state()
+        a.solve(1e-8, 200, 0)
+        a.nudge(12, 0.5)                         # a stray end velocity: restart clears it
+        a.restart()
+        assert np.array_equal(a.get_state(), init)
+        it, st = a.get_iters()
+        assert not it.any() and not st.any()
+        a.solve(1e-8, 200, 0)
+        b.solve(1e-8, 200, 0)
+        assert np.array_equal(a.get_state(), b.get_state()) and np.array_equal(a.get_iters()[0], b.get_iters()[0])
+
+
+def test_single_process_sharded_bench_prints_the_bench_keys():
+    # the C++ multi-GPU host measurable the moment a multi-GPU node exists; here on the one device
+    import json
+    n = 1 << 18
+    out = subprocess.run([EXE, "--gpus", "1", "--n", str(n), "--seed", "12345", "--bench", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "per_device_ms_per_pass"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["vs_baseline"] is None
+    p0, p1, p2 = rp.problems.generate(12345, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as b:
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 200, 0)
+        r = b.reduce()
+    assert line["config"]["newton_steps_per_pass"] == r["total_steps"] and line["config"]["converged"] == n
+    assert line["config"]["max_gap"] < 1e-8 and line["value"] > 1e9
+    assert len(line["per_device_ms_per_pass"]) == 1 and 0 < line["per_device_ms_per_pass"][0] <= line["ms_per_step"] * 1.001
