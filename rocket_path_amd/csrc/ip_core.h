@@ -140,10 +140,14 @@ template <typename T> struct Acc {
 // GT = false: the time derivatives are rebuilt at the start of the step (14 flop) -- eight registers that are then free in
 // the residual backtracking loop, the register peak of the fixed-step kernels (memoisation state on top).  GT = true
 // (gated kernels, which have the registers): they are carried too.
-template <typename T, bool GT = false> struct AccCarry {
+// RS = true (gated reference-mode kernels): also the three sums the residual test and the gate are made of, taken at
+// the accepted trial point -- X = |grad f + G^T lam|^2, Q1 = S lam_i c_i (= -gap), Q2 = S (lam_i c_i)^2; see residual_sums.
+template <typename T, bool GT = false, bool RS = false> struct AccCarry {
+    static constexpr bool has_sums = RS;
     T r0, r1;
     T a[4];
     T gt[GT ? 4 : 1];
+    T X, Q1, Q2;      // unused (and not live) unless RS
 };
 
 // d a_j / d vel1: dAdV1 of segment 0's ends (-2/t0, 4/t0), dAdV0 of segment 1's ends (-4/t1, 2/t1)
@@ -312,6 +316,56 @@ __device__ __forceinline__ T residual_norm(const Acc<T> &e, const T (&lam)[CMap<
     const T accx = fma_(rt1, rt1, fma_(rt0, rt0, rv * rv));
     return (accm + accp) + accx;
 }
+
+// The same residual in the form the gated kernels carry from step to step.  With t_i = lam_i c_i,
+//     |r(p)|^2 = X + S (t_i + p)^2 = X + Q2 + p (2 Q1 + m p),      X = |grad f + G^T lam|^2, Q1 = S t_i, Q2 = S t_i^2,
+// and the surrogate gap of the same point is -Q1.  X, Q1 and Q2 do not depend on p: evaluated once at the accepted trial
+// point they serve that step's residual test, the next step's gate and perturbation (gap = -Q1, p = gap / (10 m)) AND the
+// next step's r(x) under its new p -- the 8-constraint sweeps the reference spends on surrogateDualityGap and on
+// residualNorm at x (onedpath_ip.cpp:812, 932) cost a handful of operations.  (Q2 + p (2 Q1 + m p) cancels where the
+// point is well centred, t_i ~ -p: the complementarity part is then resolved to ~1e-15 p^2, far below anything the Armijo
+// comparison against r(x) can see -- it has to be beaten by a factor (1 - 0.01 s), not by rounding.)
+template <typename T, int VARIANT, bool TRIAL>
+__device__ __forceinline__ void residual_sums(const Acc<T> &e, const T (&lam)[CMap<VARIANT>::NC], const T (&dl)[CMap<VARIANT>::NC], T s, T L,
+                                              T &X, T &Q1, T &Q2)
+{
+    T rv = T(0), rt0 = T(1), rt1 = T(1), q1m = T(0), q1p = T(0), q2m = T(0), q2p = T(0);
+    if constexpr (VARIANT == 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T lm = TRIAL ? fma_(dl[2 * j], s, lam[2 * j]) : lam[2 * j];
+            const T lp = TRIAL ? fma_(dl[2 * j + 1], s, lam[2 * j + 1]) : lam[2 * j + 1];
+            const T d = lp - lm;
+            rv = fma_(d, acc_gv(e, j), rv);
+            if (j < 2) rt0 = fma_(d, e.gt[j], rt0);
+            else       rt1 = fma_(d, e.gt[j], rt1);
+            const T tm = lm * (-e.a[j] - L), tp = lp * (e.a[j] - L);
+            q1m += tm;
+            q1p += tp;
+            q2m = fma_(tm, tm, q2m);
+            q2p = fma_(tp, tp, q2p);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T li = TRIAL ? fma_(dl[i], s, lam[i]) : lam[i];
+            T gv, gt;
+            c_grad<T, 4>(i, e, gv, gt);
+            rv = fma_(li, gv, rv);
+            if (i < 2) rt0 = fma_(li, gt, rt0);
+            else       rt1 = fma_(li, gt, rt1);
+            const T t = li * c_value<T, 4>(i, e, L);
+            if (i & 1) { q1p += t; q2p = fma_(t, t, q2p); }
+            else       { q1m += t; q2m = fma_(t, t, q2m); }
+        }
+    }
+    X = fma_(rt1, rt1, fma_(rt0, rt0, rv * rv));
+    Q1 = q1m + q1p;
+    Q2 = q2m + q2p;
+}
+
+template <typename T, int NC>
+__device__ __forceinline__ T residual_from_sums(T X, T Q1, T Q2, T p) { return X + fma_(p, fma_(T(NC), p, Q1 + Q1), Q2); }
 
 // 3x3 solve, Gaussian elimination with partial pivoting (row of largest magnitude, first
 // wins ties), branch-free, three reciprocals.  A zero pivot means a zero column: the
@@ -574,9 +628,10 @@ __device__ __forceinline__ void direction_split(const P &k, const KParams<T> &kp
 // each step costs more, and results are NOT the reference's iterates -- opt-in, off by default.
 template <typename T, int VARIANT, class P, bool MEMO = true, bool PAIRED = false, int MU = 0>
 __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
-                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO> &c)
+                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c)
 {
     constexpr int NC = CMap<VARIANT>::NC;
+    constexpr bool SUMS = !MEMO && MU == 0;      // the residual in its carried form (residual_sums)
     const T L = kp.limit;
     const T p = gap * kp.inv_mu_den;                      // onedpath_ip.cpp:812
 
@@ -596,7 +651,8 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         }
         if constexpr (MU == 0) {
             direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
-            r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);      // onedpath_ip.cpp:932
+            if constexpr (SUMS) r0n = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
+            else r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);      // onedpath_ip.cpp:932
         } else {
             T dxa[3], dla[NC], dxc[3], dlc[NC];
             direction_split<T, VARIANT, P>(k, kp, v, lam, e, dxa, dla, dxc, dlc);
@@ -703,7 +759,13 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         if (MEMO && tv == v && tt0 == t0 && tt1 == t1) { frozen = true; break; }
         if (!et_valid) accel_values(k, tv, tt0, tt1, et);
         accel_grads(k, tv, et);
-        const T rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
+        T rn;
+        if constexpr (SUMS) {
+            residual_sums<T, VARIANT, true>(et, lam, dl, s, L, c.X, c.Q1, c.Q2);      // overwritten by every trial: the accepted one stays
+            rn = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
+        } else {
+            rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
+        }
         et_valid = false;
         if (rn <= r0n * (T(1) - kp.armijo * s)) {
             accepted = true;
@@ -762,6 +824,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     if (!accepted) {                                   // the loop ran out of halvings: its last s was never evaluated
         accel_values(k, v, t0, t1, et);
         if constexpr (!MEMO) accel_grads(k, v, et);
+        if constexpr (SUMS) residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2);
     }
     c.r0 = et.r0; c.r1 = et.r1;
 #pragma unroll

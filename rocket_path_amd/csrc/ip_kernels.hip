@@ -3,18 +3,20 @@
 // Data layout in HBM: structure of arrays.  Field f of problem i lives at
 // base[f * stride + i]; the field order is the reference's enum order (enum V,
 // onedpath_ip.cpp:15-43; enum V2, onedpath2_ip.cpp:15-39), so field 0..2 are the variables,
-// 3..3+m-1 the multipliers and the last five the constants.  A wave touches 64 consecutive
-// elements of each field: every load/store instruction is one fully used 512 B (f64) or
-// 256 B (f32) segment.  One Newton step reads 16 and writes 11 fields (F3): 216 B per
-// problem per step, the algorithmic traffic the roofline is priced against.
+// 3..3+m-1 the multipliers and the last five the constants.  The stride is an odd multiple of 512
+// elements (rp_batch.cpp: a power-of-two distance between the fields puts all of them on one HBM
+// channel).  One Newton step reads 16 and writes 11 fields (F3): 216 B per problem per step, the
+// algorithmic traffic of SURVEY.md 8d; the kernels instantiated for zero end velocities read 14.
 //
-// Three launch shapes share the per-lane step of ip_core.h, all with 256-thread blocks (4 waves,
-// 2 waves per SIMD at ~190 VGPRs) and one problem per lane:
-//   k_newton_stream  k ungated steps; grid = the resident set (512 blocks), lanes walk the batch
-//                    with that stride and prefetch the next state into registers (HBM-streaming form)
-//   k_solve_tiled    the fused gated solve; one 512-problem tile per block, staged in LDS and
-//                    scheduled by expected step count (the benchmark's kernel)
-//   k_newton         one problem per lane in batch order: small batches, host-polled gated loops
+// Launch shapes, all sharing the per-lane step of ip_core.h, all with 256-thread blocks:
+//   k_solve_tiled      the fused gated solve (the benchmark's kernel; 130 VGPRs, 3 waves per SIMD) and, ungated,
+//                      k >= 3 steps on large batches: one 512-problem tile per block, staged in LDS and
+//                      scheduled by expected step count
+//   k_newton_stream16  k <= 2 ungated steps, the HBM-streaming form: 16 B per lane (two doubles / four floats =
+//                      that many consecutive problems per lane), one global_load/store_dwordx4 per field
+//   k_newton_stream    the same with one problem per lane and a register prefetch: ragged remainders, small
+//                      batches with k >= 3 (more waves than the 16-byte form), mu_mode 1
+//   k_newton           one problem per lane in batch order, gated: small batches, host-polled gated loops, mu_mode 1
 // Problems are independent and nothing is re-read, so there is no L2 locality to arrange: the
 // plain blockIdx -> problem-range map is XCD-neutral (blocks are dealt round-robin over the 8 XCDs).
 #include "ip_kernels.h"
@@ -69,7 +71,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 #define RP_NEWTON_WAVES 2     // minimum waves per SIMD the register allocator must leave room for
 #endif
 #ifndef RP_TILED_WAVES
-#define RP_TILED_WAVES 3     // the tiled solve fits 168 VGPRs and 48 KiB of LDS per block: three blocks per CU
+#define RP_TILED_WAVES 3     // the tiled kernels fit 168 VGPRs (gated: 130) and 48 KiB of LDS per block: three blocks per CU
 #endif
 
 // The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
@@ -83,7 +85,9 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open)
 {
-    using Carry = AccCarry<T, GATED>;      // gated kernels carry the time derivatives as well (newton_step's MEMO = !GATED)
+    // gated kernels carry the time derivatives as well (newton_step's MEMO = !GATED) and, in the reference's mu mode, the
+    // residual sums, from which the gap of the current point comes for free
+    using Carry = AccCarry<T, GATED, GATED && MU == 0>;
     Carry e;            // the evaluation at the current point, carried from step to step
     auto evaluate = [&]() {
         Acc<T> e0;
@@ -95,7 +99,12 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
             accel_grads(pr, v, e0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) e.gt[j] = e0.gt[j];
+            if constexpr (Carry::has_sums) residual_sums<T, VARIANT, false>(e0, lam, lam, T(0), kp.limit, e.X, e.Q1, e.Q2);
         }
+    };
+    auto current_gap = [&]() -> T {
+        if constexpr (Carry::has_sums) return -e.Q1;
+        else return duality_gap<T, VARIANT, Carry>(e, lam, kp.limit);
     };
     evaluate();
 
@@ -104,7 +113,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     int since_best = 0;
     const T objective_in = t0 + t1;      // the objective (total duration) this launch started from: RP_ST_WRONG_WAY below
     for (int s = 0; s < k; ++s) {
-        const T gap = duality_gap<T, VARIANT, Carry>(e, lam, kp.limit);
+        const T gap = current_gap();
         if (GATED) {
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
             if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; break; }
@@ -125,7 +134,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     }
     if (GATED) {
         if (!done) {   // settle the status now so the host knows whether to launch again
-            const T gap = duality_gap<T, VARIANT, Carry>(e, lam, kp.limit);
+            const T gap = current_gap();
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; }
             else if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; }
         }
@@ -323,12 +332,13 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
 // k_order_tiles (run when positions are set, not per solve) computes for every tile of 512
 // consecutive problems a permutation of the tile ordered by the segment-length ratio
 // min|dX|/max|dX| (64-bucket counting sort in LDS).  k_solve_tiled gives each 256-thread block
-// one tile: it stages the tile's 16 fields in LDS (64 KiB, coalesced both ways -- the
-// permutation never touches global addresses), and wave w solves sorted chunks w and 7-w, so
+// one tile: it stages the tile's 11 MUTABLE fields in LDS (44 KiB in f64, coalesced both ways -- the
+// permutation never touches global addresses; the five constants are gathered once per problem inside
+// the tile's 4 KiB windows), and wave w solves sorted chunks w and 7-w, so
 // the 64 lanes of a wave hold problems of similar expected length and the four waves finish
-// together.  Idle lane-steps drop to ~5 %.  Which lane solves which problem changes nothing
-// in any problem's result (lanes never interact); a stale order (positions nudged after it
-// was computed) is merely a less effective schedule.
+// together.  Idle lane-steps drop from 19 % to 5 % (2.7 % with a perfect predictor).  Which lane solves
+// which problem changes nothing in any problem's result (lanes never interact); a stale order
+// (positions nudged after it was computed) is merely a less effective schedule.
 constexpr int kTile = 512;
 constexpr int kBuckets = 64;
 
@@ -376,10 +386,9 @@ k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__r
 
 // GATED = true: the fused gated solve.  GATED = false: k ungated steps per problem through the same tile
 // staging (for k >= 3 the arithmetic dominates, and this is the form that fits three waves per SIMD).
-// Only the default instantiations (zero end velocities, stall detector off) fit 168 VGPRs without spilling; the
-// others are held to two waves per SIMD instead (any scratch makes the launch time erratic).
+// Every instantiation fits 168 VGPRs without scratch (profiles/kernel_resources.py; any scratch makes the launch time erratic).
 template <typename S, typename T, int VARIANT, bool GATED, bool STALL, bool ZV>
-__global__ void __launch_bounds__(kBlock, (STALL || !ZV) ? 2 : RP_TILED_WAVES)
+__global__ void __launch_bounds__(kBlock, RP_TILED_WAVES)
 k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
               const uint16_t *__restrict__ order)
