@@ -137,6 +137,10 @@ RP_API int rp_batch_nudge(rp_batch *b, int var_index, double delta);
 /* k times onKey('n') = moveInteriorPoint (onedpath_ip.cpp:810-953 / onedpath2_ip.cpp:698-841)
  * on every problem, ungated, fused into one launch (state stays in registers between steps). */
 RP_API int rp_batch_step(rp_batch *b, int k);
+/* Diagnostic twin of rp_batch_step: the same k steps (same arithmetic: results are bit-identical to rp_batch_step), returning
+ * per problem how often the feasibility loop (onedpath_ip.cpp:927) and the residual loop (:944) halved the step over those k
+ * steps.  For decision-level comparisons with the reference; one problem per lane, synchronous, not a fast path. */
+RP_API int rp_batch_step_counted(rp_batch *b, int k, uint32_t *feas_halvings, uint32_t *resid_halvings);
 /* Gated solve, the convention of SURVEY.md appendix A.5 per problem:
  *     for (it = 0; it < max_iter; ++it) { if (gap < gap_tol) break; step; }
  * steps_per_launch <= 0: one fused launch (each lane loops until its own gate);

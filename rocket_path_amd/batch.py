@@ -108,6 +108,13 @@ class Batch:
     def step(self, k=1):
         capi.check(self._lib.rp_batch_step(self._h, int(k)))
 
+    def step_counted(self, k=1):
+        """k steps plus the per-problem totals of (feasibility, residual) halvings over them (diagnostic)."""
+        nf = np.empty(self.n, dtype=np.uint32)
+        nr = np.empty(self.n, dtype=np.uint32)
+        capi.check(self._lib.rp_batch_step_counted(self._h, int(k), _ptr(nf), _ptr(nr)))
+        return nf, nr
+
     def solve(self, gap_tol=1e-8, max_iter=200, steps_per_launch=0):
         capi.check(self._lib.rp_batch_solve(self._h, float(gap_tol), int(max_iter), int(steps_per_launch)))
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "rp_batch_get_state_range": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _vp]),
     "rp_batch_nudge": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_double]),
     "rp_batch_step": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "rp_batch_step_counted": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "rp_batch_solve": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
     "rp_batch_move_toward_feasibility": (ctypes.c_int, [_vp]),
     "rp_batch_get_iters": (ctypes.c_int, [_vp, _vp, _vp]),

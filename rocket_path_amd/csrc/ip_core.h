@@ -40,6 +40,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace rp {
 
 template <typename T> __device__ __forceinline__ T fma_(T a, T b, T c);
@@ -49,6 +51,10 @@ template <> __device__ __forceinline__ float fma_<float>(float a, float b, float
 template <typename T> __device__ __forceinline__ T abs_(T a);
 template <> __device__ __forceinline__ double abs_<double>(double a) { return __builtin_fabs(a); }
 template <> __device__ __forceinline__ float abs_<float>(float a) { return __builtin_fabsf(a); }
+
+template <typename T> __device__ __forceinline__ T ldexp_(T a, int e);
+template <> __device__ __forceinline__ double ldexp_<double>(double a, int e) { return __builtin_ldexp(a, e); }
+template <> __device__ __forceinline__ float ldexp_<float>(float a, int e) { return __builtin_ldexpf(a, e); }
 
 template <typename T> __device__ __forceinline__ T sqrt_(T a);
 template <> __device__ __forceinline__ double sqrt_<double>(double a) { return __builtin_sqrt(a); }
@@ -608,6 +614,20 @@ __device__ __forceinline__ void direction_split(const P &k, const KParams<T> &kp
     }
 }
 
+// Line-search bookkeeping for the diagnostic kernel (rp_batch_step_counted): executions of `s *= 0.5` in the feasibility
+// loop (onedpath_ip.cpp:927) and in the residual loop (:944) -- the two numbers the oracle's orc_step_info reports.
+struct NoDiag {
+    __device__ __forceinline__ void feas() {}
+    __device__ __forceinline__ void resid() {}
+    __device__ __forceinline__ void moving() {}
+};
+struct HalvingDiag {
+    unsigned nf = 0, nr = 0, nm = 0;      // nm: residual trials that needed a full evaluation (trial point != x); tuning only
+    __device__ __forceinline__ void feas() { ++nf; }
+    __device__ __forceinline__ void resid() { ++nr; }
+    __device__ __forceinline__ void moving() { ++nm; }
+};
+
 // ---- one Newton step -------------------------------------------------------------------
 // In:  x = (v, t0, t1), lam, c = reciprocals + accelerations at x, gap = surrogate duality gap at x.
 // Out: the same at the new point (the caller recomputes the gap from c).
@@ -616,8 +636,9 @@ __device__ __forceinline__ void direction_split(const P &k, const KParams<T> &kp
 // (the reference recomputes the same numbers); what it buys is the reference's post-convergence regime, where x no
 // longer moves and every step still walks ~48 residual halvings (onedpath_ip.cpp:932-945) -- fixed-step runs.  A gated
 // solve stops long before that regime, so its kernels are built without the checks.
-// PAIRED (with MEMO): the post-convergence residual loop evaluates two step lengths per trip; for the kernels that run
-// small batches (one wave per SIMD) and have the registers for it.
+// PAIRED (with MEMO; the name is historical): the post-convergence loop runs on the affine pieces of the residual (44 more
+// registers: the one-problem-per-lane streaming kernels, which run the small fixed-step batches, have them; the tiled
+// kernels at 168 VGPRs do not).
 //
 // MU (rp_params.mu_mode): 0 = the reference's fixed centring, p = gap / (m * mu_divisor) (onedpath_ip.cpp:812) -- the only
 // mode the parity tests are about.  1 = centring by trial: with the split direction d(p) = d_a + p d_c, the candidates
@@ -626,9 +647,10 @@ __device__ __forceinline__ void direction_split(const P &k, const KParams<T> &kp
 // residual of its own p passes the reference's Armijo test) succeeds; otherwise the reference step is taken with the
 // reference's line search.  Fewer steps to the same optimum (measured: 15.4 -> 12.7 mean on the benchmark distribution);
 // each step costs more, and results are NOT the reference's iterates -- opt-in, off by default.
-template <typename T, int VARIANT, class P, bool MEMO = true, bool PAIRED = false, int MU = 0>
+template <typename T, int VARIANT, class P, bool MEMO = true, bool PAIRED = false, int MU = 0, class D = NoDiag>
 __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
-                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c)
+                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c,
+                                            D &diag)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr bool SUMS = !MEMO && MU == 0;      // the residual in its carried form (residual_sums)
@@ -738,6 +760,20 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         if (MEMO && tv == v && tt0 == t0 && tt1 == t1) {
             ok = feasible_here;            // same point, same answer
             et_valid = false;
+            if (!ok) {
+                // x itself fails the test by a rounding (|a| = L + 1 ulp: the residual loop of the previous step accepts
+                // points the feasibility loop never saw, as the reference's does) and every smaller s gives x again: the
+                // reference walks all its remaining halvings to the same verdict.  So does this, without the evaluations.
+                if (kp.backtrack == T(0.5) && std::is_same<D, NoDiag>::value) {
+                    s = ldexp_(s, it - kp.max_bt);      // max_bt - it exact halvings at once
+                } else {
+                    for (; it < kp.max_bt; ++it) {
+                        s *= kp.backtrack;
+                        diag.feas();
+                    }
+                }
+                break;
+            }
         } else {
             accel_values(k, tv, tt0, tt1, et);
             ok = all_satisfied<T, VARIANT>(et, L);
@@ -745,6 +781,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         }
         if (ok) break;
         s *= kp.backtrack;
+        diag.feas();
         et_valid = false;
     }
 
@@ -759,6 +796,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         if (MEMO && tv == v && tt0 == t0 && tt1 == t1) { frozen = true; break; }
         if (!et_valid) accel_values(k, tv, tt0, tt1, et);
         accel_grads(k, tv, et);
+        diag.moving();
         T rn;
         if constexpr (SUMS) {
             residual_sums<T, VARIANT, true>(et, lam, dl, s, L, c.X, c.Q1, c.Q2);      // overwritten by every trial: the accepted one stays
@@ -772,6 +810,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
             break;
         }
         s *= kp.backtrack;
+        diag.resid();
     }
     if constexpr (MEMO) {
         if (frozen) {
@@ -781,27 +820,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 #pragma unroll
             for (int j = 0; j < 4; ++j) et.a[j] = c.a[j];
             accel_grads(k, v, et);
-            if constexpr (PAIRED) {
-                // Two step lengths per trip, s and s/2, accepted in the reference's order.  A small fixed-step batch runs
-                // one wave per SIMD, where a single chain of dependent fp64 operations leaves the pipe idle most of the
-                // time: the second evaluation is independent work in the gaps (and half the loop overhead).
-                for (; it < kp.max_bt; it += 2) {
-                    const T s2 = s * kp.backtrack;
-                    const T rn1 = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
-                    const T rn2 = residual_norm<T, VARIANT, true>(et, lam, dl, s2, p, L);
-                    if (rn1 <= r0n * (T(1) - kp.armijo * s)) {
-                        accepted = true;
-                        break;
-                    }
-                    s = s2;
-                    if (it + 1 >= kp.max_bt) break;
-                    if (rn2 <= r0n * (T(1) - kp.armijo * s2)) {
-                        accepted = true;
-                        break;
-                    }
-                    s = s2 * kp.backtrack;
-                }
-            } else {
+            if constexpr (!PAIRED) {      // the kernels without the registers for the affine pieces: the direct evaluation
                 for (; it < kp.max_bt; ++it) {
                     const T rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
                     if (rn <= r0n * (T(1) - kp.armijo * s)) {
@@ -809,7 +828,85 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
                         break;
                     }
                     s *= kp.backtrack;
+                    diag.resid();
                 }
+            } else {
+            // With x fixed the residual vector is AFFINE in s: every component is r_i(0) + s r_i'.  The pieces are formed
+            // once per step; a halving is then 11 multiply-adds for the components and the same sum of squares, in the same
+            // order, as residual_norm -- so that once s r_i' drops below half an ulp the loop sees r(x) bit for bit, as the
+            // direct evaluation does (that is what ends the reference's loop after ~48 halvings, onedpath_ip.cpp:941).
+            T rv0 = T(0), rv1 = T(0), ra0 = T(1), ra1 = T(0), rb0 = T(1), rb1 = T(0);
+            T c0[NC], c1[NC];
+            if constexpr (VARIANT == 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const T d0 = lam[2 * q + 1] - lam[2 * q], d1 = dl[2 * q + 1] - dl[2 * q];
+                    rv0 = fma_(d0, acc_gv(et, q), rv0);
+                    rv1 = fma_(d1, acc_gv(et, q), rv1);
+                    if (q < 2) { ra0 = fma_(d0, et.gt[q], ra0); ra1 = fma_(d1, et.gt[q], ra1); }
+                    else       { rb0 = fma_(d0, et.gt[q], rb0); rb1 = fma_(d1, et.gt[q], rb1); }
+                    const T cm = -et.a[q] - L, cp = et.a[q] - L;
+                    c0[2 * q] = fma_(lam[2 * q], cm, p);
+                    c1[2 * q] = dl[2 * q] * cm;
+                    c0[2 * q + 1] = fma_(lam[2 * q + 1], cp, p);
+                    c1[2 * q + 1] = dl[2 * q + 1] * cp;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    T gv, gt;
+                    c_grad<T, 4>(i, et, gv, gt);
+                    rv0 = fma_(lam[i], gv, rv0);
+                    rv1 = fma_(dl[i], gv, rv1);
+                    if (i < 2) { ra0 = fma_(lam[i], gt, ra0); ra1 = fma_(dl[i], gt, ra1); }
+                    else       { rb0 = fma_(lam[i], gt, rb0); rb1 = fma_(dl[i], gt, rb1); }
+                    const T ci = c_value<T, 4>(i, et, L);
+                    c0[i] = fma_(lam[i], ci, p);
+                    c1[i] = dl[i] * ci;
+                }
+            }
+            auto affine_rn = [&](T sq) -> T {
+                T accm = T(0), accp = T(0);
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const T ri = fma_(c1[i], sq, c0[i]);
+                    if (i & 1) accp = fma_(ri, ri, accp);
+                    else       accm = fma_(ri, ri, accm);
+                }
+                const T rv = fma_(rv1, sq, rv0), ra = fma_(ra1, sq, ra0), rb = fma_(rb1, sq, rb0);
+                return (accm + accp) + fma_(rb, rb, fma_(ra, ra, rv * rv));
+            };
+            // W step lengths per trip (s and its next W - 1 halvings), accepted in the reference's order.  A lone wave on its
+            // SIMD is bound by the latency of one evaluation's dependent chain; all W evaluations are complete before the
+            // one branch of the trip, so they fill each other's gaps.
+            constexpr int W = 2;      // measured at 65,536 problems x 50 steps: W = 1 0.545 ms, W = 2 0.332 ms, W = 4 0.352 ms
+            while (it < kp.max_bt) {
+                T sk[W], rn[W];
+                sk[0] = s;
+#pragma unroll
+                for (int q = 1; q < W; ++q) sk[q] = sk[q - 1] * kp.backtrack;
+#pragma unroll
+                for (int q = 0; q < W; ++q) rn[q] = affine_rn(sk[q]);
+                const int valid = (kp.max_bt - it < W) ? kp.max_bt - it : W;      // trials the reference would still make
+                int first = W;                                                    // first accepted trial of this trip
+#pragma unroll
+                for (int q = W - 1; q >= 0; --q)
+                    if (q < valid && rn[q] <= r0n * (T(1) - kp.armijo * sk[q])) first = q;
+                const bool got = first < W;
+                const int halved = got ? first : valid;
+                T snew = sk[W - 1] * kp.backtrack;                                // all W failed
+#pragma unroll
+                for (int q = W - 1; q >= 0; --q)
+                    if (halved == q) snew = sk[q];
+                s = snew;
+                if constexpr (!std::is_same<D, NoDiag>::value)
+                    for (int q = 0; q < halved; ++q) diag.resid();
+                it += halved;
+                if (got) {
+                    accepted = true;
+                    break;
+                }
+            }
             }
         }
     }
@@ -833,6 +930,15 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 #pragma unroll
         for (int j = 0; j < 4; ++j) c.gt[j] = et.gt[j];
     }
+}
+
+// the common call: no bookkeeping
+template <typename T, int VARIANT, class P, bool MEMO = true, bool PAIRED = false, int MU = 0>
+__device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
+                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c)
+{
+    NoDiag none;
+    newton_step<T, VARIANT, P, MEMO, PAIRED, MU, NoDiag>(k, kp, gap, v, t0, t1, lam, c, none);
 }
 
 }  // namespace rp

@@ -38,6 +38,8 @@ inline int num_constraints(int variant) { return variant == 4 ? 4 : 8; }
 
 // k ungated Newton steps per problem, one launch.
 hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStream_t stream);
+// k ungated steps with the per-problem halving totals of both line-search loops (diagnostic twin of launch_steps)
+hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k, uint32_t *d_nfeas, uint32_t *d_nresid, hipStream_t stream);
 // up to k gated steps per problem (k = max_iter gives the fused solve); zeroes counters[0] first.
 hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream);
 // the fused solve (every problem to its gate in one launch), tiled and ordered by expected step count

@@ -273,6 +273,62 @@ k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
 }
 
 // ---------------------------------------------------------------------------------------
+// Diagnostic twin of the ungated step (rp_batch_step_counted): one problem per lane, k steps, the same arithmetic as
+// k_newton_stream, plus the per-problem totals of feasibility and residual halvings -- what the oracle's orc_step_info
+// counts -- so that the line search can be compared decision for decision, not only through the states.
+template <typename S, typename T, int VARIANT>
+__global__ void __launch_bounds__(kBlock)
+k_newton_counted(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, uint32_t *__restrict__ nfeas, uint32_t *__restrict__ nresid)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    constexpr int CB = 3 + NC;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    S *f = base + i;
+    T v = (T)f[0 * stride], t0 = (T)f[1 * stride], t1 = (T)f[2 * stride];
+    T lam[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) lam[c] = (T)f[(3 + c) * stride];
+    Prob<T, false> pr;
+    const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
+    pr.v0 = (T)f[(CB + 1) * stride];
+    pr.v2 = (T)f[(CB + 4) * stride];
+    pr.dx0 = p1 - p0;
+    pr.dx1 = p2 - p1;
+    AccCarry<T, false, false> e;
+    auto evaluate = [&]() {
+        Acc<T> e0;
+        accel_values(pr, v, t0, t1, e0);
+        e.r0 = e0.r0; e.r1 = e0.r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e.a[j] = e0.a[j];
+    };
+    evaluate();
+    HalvingDiag diag;
+    for (int s = 0; s < k; ++s) {
+        const T gap = duality_gap<T, VARIANT, AccCarry<T, false, false>>(e, lam, kp.limit);
+        newton_step<T, VARIANT, Prob<T, false>, true, true, 0, HalvingDiag>(pr, kp, gap, v, t0, t1, lam, e, diag);
+        if constexpr (sizeof(S) != sizeof(T)) {
+            v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) lam[c] = (T)(S)lam[c];
+            evaluate();
+        }
+    }
+    f[0 * stride] = (S)v;
+    f[1 * stride] = (S)t0;
+    f[2 * stride] = (S)t1;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = (S)lam[c];
+#ifdef RP_DIAG_MOVING      // tuning build: full residual evaluations instead of feasibility halvings
+    nfeas[i] = diag.nm;
+#else
+    nfeas[i] = diag.nf;
+#endif
+    nresid[i] = diag.nr;
+}
+
+// ---------------------------------------------------------------------------------------
 // The same streaming step with 16-byte accesses: a lane owns 16 / sizeof(S) CONSECUTIVE problems (two doubles, four
 // floats), loads each field of all of them with one global_load_dwordx4 (a wave moves 1 KiB per instruction), steps
 // them one after the other and stores each mutable field with one global_store_dwordx4.  No prefetch registers:
@@ -312,7 +368,7 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, true>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
         f[0][c] = (S)v;
         f[1][c] = (S)t0;
         f[2][c] = (S)t1;
@@ -879,6 +935,13 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
         RP_DISPATCH_Z(w, hipLaunchKernelGGL((k_newton_stream<S, T, V, Z>), dim3(grid), dim3(kBlock), 0, stream,
                                              (S *)w.base, w.stride, w.n, k, make_kparams<T>(hp, V)));
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k, uint32_t *d_nfeas, uint32_t *d_nresid, hipStream_t stream)
+{
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_newton_counted<S, T, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                       (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), d_nfeas, d_nresid));
     return hipGetLastError();
 }
 

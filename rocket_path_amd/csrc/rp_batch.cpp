@@ -422,6 +422,25 @@ int rp_batch_step(rp_batch *b, int k)
     return RP_OK;
 }
 
+int rp_batch_step_counted(rp_batch *b, int k, uint32_t *feas_halvings, uint32_t *resid_halvings)
+{
+    RP_NEED(b);
+    if (k < 0 || k > 1000000) return fail(RP_ERR_INVALID, "step count %d out of range (0..1000000)", k);
+    if (!feas_halvings || !resid_halvings) return fail(RP_ERR_INVALID, "null output");
+    if (b->params.mu_mode != 0) return fail(RP_ERR_UNSUPPORTED, "the counted step exists for the reference's mu mode only");
+    const size_t n = b->view.n;
+    uint32_t *d = nullptr;
+    RP_HIP(hipMalloc((void **)&d, 2 * n * sizeof(uint32_t)));
+    hipError_t e = rp::launch_steps_counted(b->view, b->params, k, d, d + n, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(feas_halvings, d, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(resid_halvings, d + n, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RP_ERR_DEVICE, "rp_batch_step_counted: %s", hipGetErrorString(e));
+    b->ungated_steps += (double)k;
+    return RP_OK;
+}
+
 int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_launch)
 {
     RP_NEED(b);

@@ -742,3 +742,34 @@ def test_f4_wrong_way_settling_is_flagged_with_the_stall_detector_on():
         c.solve(1e-8, 200, 0)
         _, st3 = c.get_iters()
     assert np.all(st3 == rp.ST_CONVERGED)
+
+
+# ---------------------------------------------------------------- decision-level parity of the line search
+def test_halving_counts_equal_the_oracles_step_by_step(oracle):
+    # rp_batch_step_counted = rp_batch_step + how often each of the two backtracking loops halved the step
+    # (onedpath_ip.cpp:927, 944): the same counts as the oracle's orc_step_info, problem by problem, step by step,
+    # for as long as the iteration is above rounding level (gap >= ~1e-11: the first 16 steps of this distribution;
+    # from ~step 19 on both sides take their decisions on the last bit of |a| - L and on whether lam + s dlam still
+    # rounds to lam, and the counts are noise on both -- profiles/r2_halving_probe.log).
+    n = 2048
+    p0, p1, p2 = rp.problems.generate(12345, 0, n, rp.problems.DIST_MONOTONE)
+    aos = oracle.batch_init_feasible(3, p0, p1, p2)
+    info = StepInfo()
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0, p1, p2)
+        tot_f = tot_r = 0
+        for s in range(16):
+            nf, nr = a.step_counted(1)
+            b.step(1)
+            of = np.zeros(n, dtype=np.uint32)
+            orr = np.zeros(n, dtype=np.uint32)
+            for i in range(n):
+                oracle.step(3, aos[i], info)
+                of[i], orr[i] = info.feas_halvings, info.resid_halvings
+            assert np.array_equal(nf, of) and np.array_equal(nr, orr), s
+            tot_f += int(of.sum())
+            tot_r += int(orr.sum())
+        assert tot_f > 3000                                   # the comparison is not vacuous: ~0.2 halvings per step
+        assert np.array_equal(a.get_state(), b.get_state())   # the counted twin computes the very same steps
+        assert np.array_equal(a.get_iters()[0], b.get_iters()[0])
