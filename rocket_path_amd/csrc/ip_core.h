@@ -129,10 +129,12 @@ template <typename T, bool ZV = false> struct Prob {
     T v0, v2;      // vel0X, vel2X (unused when ZV)
     T dx0, dx1;    // pos1X - pos0X, pos2X - pos1X
 };
-template <typename T, class P> __device__ __forceinline__ T seg0_m(const P &k, T v) { if constexpr (P::zero_vel) return T(-2) * v; else return fma_(T(-4), k.v0, T(-2) * v); }   // v0*-4 + v1*-2
+// The velocity combinations of the four end accelerations (v0*-4 + v1*-2 etc., onedpath_ip.cpp:387, 428).  With zero end
+// velocities they are multiples of vel1 by powers of two, formed once (v2 = 2v, v4 = 4v, v8 = 8v: exact) and signed for free.
+template <typename T, class P> __device__ __forceinline__ T seg0_m(const P &k, T v) { if constexpr (P::zero_vel) return -(v + v); else return fma_(T(-4), k.v0, T(-2) * v); }   // v0*-4 + v1*-2
 template <typename T, class P> __device__ __forceinline__ T seg0_n(const P &k, T v) { if constexpr (P::zero_vel) return T(4) * v; else return fma_(T(2), k.v0, T(4) * v); }      // v0*2 + v1*4
-template <typename T, class P> __device__ __forceinline__ T seg1_m(const P &k, T v) { if constexpr (P::zero_vel) return T(-4) * v; else return fma_(T(-4), v, T(-2) * k.v2); }   // segment 1: v0 = vel1, v1 = vel2
-template <typename T, class P> __device__ __forceinline__ T seg1_n(const P &k, T v) { if constexpr (P::zero_vel) return T(2) * v; else return fma_(T(2), v, T(4) * k.v2); }
+template <typename T, class P> __device__ __forceinline__ T seg1_m(const P &k, T v) { if constexpr (P::zero_vel) return -(T(4) * v); else return fma_(T(-4), v, T(-2) * k.v2); }   // segment 1: v0 = vel1, v1 = vel2
+template <typename T, class P> __device__ __forceinline__ T seg1_n(const P &k, T v) { if constexpr (P::zero_vel) return v + v; else return fma_(T(2), v, T(4) * k.v2); }
 
 // End accelerations of both segments and their first derivatives at one (v, t0, t1).
 // index j: 0 = segment 0 initial, 1 = segment 0 final, 2 = segment 1 initial, 3 = segment 1 final
@@ -209,10 +211,13 @@ __device__ __forceinline__ void accel_hess(const P &k, T v, const Acc<T> &e, T (
     const T m1 = seg1_m<T>(k, v), n1 = seg1_n<T>(k, v);
     const T q0 = r0 * r0, q1 = r1 * r1;
     const T c0 = q0 * r0, c1 = q1 * r1;
-    htt[0] = fma_(T(36), u0, T(2) * m0) * c0;      // (36 dX/t - 8 v0 - 4 v1) / t^3
-    htt[1] = fma_(T(-36), u0, T(2) * n0) * c0;     // (-36 dX/t + 4 v0 + 8 v1) / t^3
-    htt[2] = fma_(T(36), u1, T(2) * m1) * c1;
-    htt[3] = fma_(T(-36), u1, T(2) * n1) * c1;
+    T m0d, n0d, m1d, n1d;      // 2 m0, 2 n0, 2 m1, 2 n1
+    if constexpr (P::zero_vel) { m0d = m1; n0d = T(8) * v; m1d = -n0d; n1d = n0; }      // -4v, 8v, -8v, 4v: already there
+    else { m0d = T(2) * m0; n0d = T(2) * n0; m1d = T(2) * m1; n1d = T(2) * n1; }
+    htt[0] = fma_(T(36), u0, m0d) * c0;      // (36 dX/t - 8 v0 - 4 v1) / t^3
+    htt[1] = fma_(T(-36), u0, n0d) * c0;     // (-36 dX/t + 4 v0 + 8 v1) / t^3
+    htt[2] = fma_(T(36), u1, m1d) * c1;
+    htt[3] = fma_(T(-36), u1, n1d) * c1;
     htv[0] = T(2) * q0;       // sTV1, initial end
     htv[1] = T(-4) * q0;      // sTV1, final end
     htv[2] = T(4) * q1;       // sTV0, initial end
@@ -636,7 +641,7 @@ struct HalvingDiag {
 // (the reference recomputes the same numbers); what it buys is the reference's post-convergence regime, where x no
 // longer moves and every step still walks ~48 residual halvings (onedpath_ip.cpp:932-945) -- fixed-step runs.  A gated
 // solve stops long before that regime, so its kernels are built without the checks.
-// PAIRED (with MEMO; the name is historical): the post-convergence loop runs on the affine pieces of the residual (44 more
+// AFFINE (with MEMO): the post-convergence loop runs on the affine pieces of the residual (44 more
 // registers: the one-problem-per-lane streaming kernels, which run the small fixed-step batches, have them; the tiled
 // kernels at 168 VGPRs do not).
 //
@@ -647,7 +652,7 @@ struct HalvingDiag {
 // residual of its own p passes the reference's Armijo test) succeeds; otherwise the reference step is taken with the
 // reference's line search.  Fewer steps to the same optimum (measured: 15.4 -> 12.7 mean on the benchmark distribution);
 // each step costs more, and results are NOT the reference's iterates -- opt-in, off by default.
-template <typename T, int VARIANT, class P, bool MEMO = true, bool PAIRED = false, int MU = 0, class D = NoDiag>
+template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag>
 __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
                                             T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c,
                                             D &diag)
@@ -820,7 +825,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 #pragma unroll
             for (int j = 0; j < 4; ++j) et.a[j] = c.a[j];
             accel_grads(k, v, et);
-            if constexpr (!PAIRED) {      // the kernels without the registers for the affine pieces: the direct evaluation
+            if constexpr (!AFFINE) {      // the kernels without the registers for the affine pieces: the direct evaluation
                 for (; it < kp.max_bt; ++it) {
                     const T rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
                     if (rn <= r0n * (T(1) - kp.armijo * s)) {
@@ -933,12 +938,12 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 }
 
 // the common call: no bookkeeping
-template <typename T, int VARIANT, class P, bool MEMO = true, bool PAIRED = false, int MU = 0>
+template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0>
 __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
                                             T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c)
 {
     NoDiag none;
-    newton_step<T, VARIANT, P, MEMO, PAIRED, MU, NoDiag>(k, kp, gap, v, t0, t1, lam, c, none);
+    newton_step<T, VARIANT, P, MEMO, AFFINE, MU, NoDiag>(k, kp, gap, v, t0, t1, lam, c, none);
 }
 
 }  // namespace rp

@@ -80,7 +80,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 // S = storage type of the batch.  When it differs from the compute type T (fp32 state, fp64 arithmetic) the state is
 // rounded to S after every step, so that a step is a function "S state -> S state" whatever the launch shape:
 // step(k) stays bit-identical to k x step(1).
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool PAIRED = false, int MU = 0>
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open)
@@ -122,7 +122,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                 else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
             }
         }
-        newton_step<T, VARIANT, P, !GATED, PAIRED, MU>(pr, kp, gap, v, t0, t1, lam, e);      // gated solves never reach the regime the memoisation is for
+        newton_step<T, VARIANT, P, !GATED, AFFINE, MU>(pr, kp, gap, v, t0, t1, lam, e);      // gated solves never reach the regime the memoisation is for
         if constexpr (sizeof(S) != sizeof(T)) {
             v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
 #pragma unroll
