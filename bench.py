@@ -241,7 +241,9 @@ def main():
     steps_per_launch = steps_local / max(K, 1)
     alg_gbs = B_ALG_F3 * steps_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = profile_number(PROFILE_TAG + "_hbm_traffic.json", "k_solve_tiled_f3_f64", "hbm_bytes_per_launch")
-    flop_per_step, flop_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_flop_per_newton_step")
+    flop_per_step, flop_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_flop_per_gated_newton_step")      # the gated kernel itself
+    if flop_per_step is None:
+        flop_per_step, flop_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_flop_per_newton_step")
     if flop_per_step is None:
         flop_per_step, flop_src = 560.0, "estimate (no profiles/%s_sq_counters.json)" % PROFILE_TAG
     tflops = flop_per_step * steps_per_launch / (kernel_ms * 1e-3) / 1e12

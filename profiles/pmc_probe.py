@@ -5,7 +5,8 @@ known number of steps at 1 Mi problems:
     F3 f64          12 fused ungated steps   -> k_solve_tiled<double, double, 3, false, ...>
     F4 f32          12 fused ungated steps   -> k_solve_tiled<float, float, 4, false, ...>
     F4 f32 state    12 fused ungated steps   -> k_solve_tiled<float, double, 4, false, ...>
-followed by the benchmark's gated solve (occupancy / busy counters of the real kernel) and one k = 1 launch."""
+then the gated kernel on 524,288 identical default problems (15 steps each: its instructions per step without idle lanes),
+the benchmark's gated solve (occupancy / busy counters of the real launch) and one k = 1 launch."""
 import os
 import sys
 
@@ -22,6 +23,14 @@ for variant, dtype in ((rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F
             b.set_problems(p0, p1, p2)
             b.step(STEPS)
             b.sync()
+# the gated kernel with every lane doing the same work: 524,288 copies of the default problem (15 steps each, no idle
+# lane-steps), told apart from the benchmark's launch by its grid size
+with rp.Batch(N // 2) as b:
+    for _ in range(2):
+        b.init_default()
+        b.solve(1e-8, 200, 0)
+        b.sync()
+    assert int(b.reduce()["total_steps"]) == 15 * (N // 2)
 with rp.Batch(N) as b:
     for _ in range(2):
         b.set_problems(p0, p1, p2)

@@ -1,3 +1,5 @@
+# built with -DRP_DIAG_MOVING (make HIPFLAGS="... -DRP_DIAG_MOVING"): rp_batch_step_counted then returns the number of full residual
+# evaluations (trial point != x) in place of the feasibility halvings
 import os, sys
 import numpy as np
 sys.path.insert(0, '/root/repo')

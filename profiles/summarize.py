@@ -28,9 +28,12 @@ def one(d, pat):
 shutil.copy(one(stats_dir, "*_kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_kernel_stats.csv" % tag))
 
 
-def counters(d):
+def counters(d, grid=None):
+    """Mean counter values per kernel; grid: only dispatches of that many work-items, else all."""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(one(d, "*_counter_collection.csv"))):
+        if grid is not None and int(r["Grid_Size"]) != grid:
+            continue
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
 
@@ -103,6 +106,20 @@ for name, c in sq.items():
         top["_flop_per_f4_step_f32"] = f32 + f64
     elif name.startswith("k_solve_tiled<float, double, 4"):
         top["_flop_per_f4_step_f32state"] = f64
+# the gated kernel on 524,288 identical default problems (pmc_probe.py): 15 steps per problem, no idle lanes
+ident = {}
+for d in sq_dirs:
+    for k, cs in counters(d, grid=(N // 2) // 2).items():      # 512 problems per 256-thread block
+        if short(k).startswith("k_solve_tiled<double, double, 3, true"):
+            ident.update(cs)
+if "SQ_INSTS_VALU_FMA_F64" in ident:
+    ls = 15.0 * (N // 2)
+    ident["flop_f64_per_lane_step"] = 64.0 * (2 * ident["SQ_INSTS_VALU_FMA_F64"] + ident["SQ_INSTS_VALU_MUL_F64"] + ident["SQ_INSTS_VALU_ADD_F64"]
+                                             + ident["SQ_INSTS_VALU_TRANS_F64"]) / ls
+    if "SQ_INSTS_VALU" in ident:
+        ident["valu_insts_per_lane_step"] = 64.0 * ident["SQ_INSTS_VALU"] / ls
+    sq["k_solve_tiled<double, double, 3, true, false, true> on identical problems"] = ident
+    top["_flop_per_gated_newton_step"] = ident["flop_f64_per_lane_step"]
 sq.update(top)
 json.dump({"_method": "rocprofv3 --pmc <SQ counters, <= 8 per pass> -- python3 profiles/pmc_probe.py (1 Mi problems: 12 fused ungated steps "
                       "of F3 f64 / F4 f32 / F4 f32-state, then the fused gated F3 solve and one k = 1 launch); SQ_WAVE_CYCLES / "
