@@ -773,3 +773,29 @@ def test_halving_counts_equal_the_oracles_step_by_step(oracle):
         assert tot_f > 3000                                   # the comparison is not vacuous: ~0.2 halvings per step
         assert np.array_equal(a.get_state(), b.get_state())   # the counted twin computes the very same steps
         assert np.array_equal(a.get_iters()[0], b.get_iters()[0])
+
+
+@pytest.mark.parametrize("variant,dist,steps", [(rp.VARIANT_F3, rp.problems.DIST_NON_MONOTONE, 12), (rp.VARIANT_F3, rp.problems.DIST_REFERENCE_LIKE, 14),
+                                                (rp.VARIANT_F4, rp.problems.DIST_MONOTONE, 10)])
+def test_halving_counts_on_the_other_distributions_and_f4(oracle, variant, dist, steps):
+    # the same decision-level comparison on the stress / reference-like sets and on F4 (whose line search is the busy one:
+    # several feasibility halvings per step from step ~4 on)
+    n = 1024
+    p0, p1, p2 = rp.problems.generate(4711, 0, n, dist)
+    aos = oracle.batch_init_feasible(variant, p0, p1, p2)
+    info = StepInfo()
+    mism = total = 0
+    with rp.Batch(n, variant) as a:
+        a.set_problems(p0, p1, p2)
+        for s in range(steps):
+            nf, nr = a.step_counted(1)
+            for i in range(n):
+                oracle.step(variant, aos[i], info)
+                mism += int(nf[i] != info.feas_halvings) + int(nr[i] != info.resid_halvings)
+                total += info.feas_halvings + info.resid_halvings
+        st = a.get_state()
+    assert total > 200
+    assert mism == 0, "%d of %d decisions differ" % (mism, 2 * n * steps)
+    # F4 trajectories are chaotic (rounding-level differences grow ~10x every few steps; parity of its states
+    # is pinned per step from identical states, test_f4_fp64_single_steps): after 10 steps only the decisions are compared tightly
+    assert serr(st[:, :3], aos[:, :3]) < (TOL if variant == rp.VARIANT_F3 else 1e-5)
