@@ -282,8 +282,14 @@ def main():
             "flop_per_newton_step": flop_per_step, "flop_per_newton_step_source": flop_src,
             "avg_launch_ms": kernel_ms, "newton_steps_per_launch": steps_per_launch,
             "traffic": traffic, "traffic_source": traffic_src,
-            "note": "idle lane-steps of the gated solve (~5 %) are not counted as flops; traffic = HBM bytes per launch from "
-                    "FETCH_SIZE (x2, calibrated) + WRITE_SIZE: each state crosses HBM once per solve",
+            "note": "flop actually executed by the timed kernel (SQ counters of the same kernel on identical problems, per lane-step); "
+                    "idle lane-steps of the gated solve (~5 %) are not counted; traffic = HBM bytes per launch from FETCH_SIZE (x2, "
+                    "calibrated) + WRITE_SIZE: each state crosses HBM once per solve.  A step got cheaper in round 2 (609 -> 537 flop in "
+                    "the fixed-step kernels, 453 in the gated one, which carries its residual sums), so this fraction FALLS while steps/s "
+                    "rise: the vector ALU is issue-saturated either way (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.32 x 3 resident waves)",
+            "same_rate_at_round1_operation_count": {"flop_per_newton_step": 609.4, "achieved": 609.4 * steps_per_launch / (kernel_ms * 1e-3) / 1e12,
+                                                    "frac": 609.4 * steps_per_launch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                                    "note": "what the round-1 kernel would have had to sustain for this step rate (for comparison across rounds only)"},
             # SURVEY 8d's definition, kept as a labelled secondary: algorithmic bytes (216 B x Newton steps executed in
             # the launch) / launch time.  Not a fraction of anything for a fused launch -- see per_step_launch.
             "hbm_algorithmic": {

@@ -120,3 +120,20 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert "{" not in r.stdout          # no JSON line is ever printed from a CPU run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "one process per GPU" in (r.stderr + r.stdout)
+
+
+def test_python_constants_mirror_the_header():
+    text = open(os.path.join(ROOT, "include", "rp_batch.h")).read()
+    defs = dict(re.findall(r"#define\s+(RP_\w+)\s+(\d+)u?\b", text))
+    assert int(defs["RP_DTYPE_F64"]) == capi.DTYPE_F64 and int(defs["RP_DTYPE_F32"]) == capi.DTYPE_F32
+    assert int(defs["RP_DTYPE_F32_STATE"]) == capi.DTYPE_F32_STATE
+    for name in ("CONVERGED", "MAXITER", "NONFINITE", "INFEASIBLE", "STALLED", "WRONG_WAY"):
+        assert int(defs["RP_ST_" + name]) == getattr(capi, "ST_" + name), name
+    # rp_params and its ctypes mirror: same fields, same order
+    body = text[text.index("typedef struct {", text.index("Solver constants")):text.index("} rp_params;")]
+    fields = re.findall(r"^\s*(?:double|int32_t)\s+(\w+)(?:\[\d+\])?;", body, flags=re.M)
+    assert fields == [f[0] for f in capi.Params._fields_]
+    lib = capi.load_library()
+    p = capi.Params()
+    lib.rp_params_default(ctypes.byref(p))
+    assert p.mu_mode == 0 and p.stall_window == 0 and tuple(p.mu_sigma_try) == (0.01, 0.03)
