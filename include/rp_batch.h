@@ -148,6 +148,10 @@ RP_API int rp_batch_step_counted(rp_batch *b, int k, uint32_t *feas_halvings, ui
  * device counter after each launch; synchronous).  Iteration counts accumulate across calls
  * until the next init/set_state. */
 RP_API int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_launch);
+/* ONE asynchronous launch of up to k gated steps per still-open problem, no host polling: the building block of a solve
+ * whose convergence check is global (multi-GPU: launch on every shard, all-reduce the summaries, repeat -- SURVEY.md 8d, C4;
+ * rocket_path_amd/sharding.py, solve_with_global_checks). */
+RP_API int rp_batch_solve_launch(rp_batch *b, double gap_tol, int max_iter, int k);
 /* The Space key, moveTowardFeasibility (onedpath_ip.cpp:648-721), on every problem. */
 RP_API int rp_batch_move_toward_feasibility(rp_batch *b);
 

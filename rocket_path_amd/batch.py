@@ -118,6 +118,10 @@ class Batch:
     def solve(self, gap_tol=1e-8, max_iter=200, steps_per_launch=0):
         capi.check(self._lib.rp_batch_solve(self._h, float(gap_tol), int(max_iter), int(steps_per_launch)))
 
+    def solve_launch(self, gap_tol=1e-8, max_iter=200, k=1):
+        """One asynchronous launch of up to k gated steps per open problem (no host polling)."""
+        capi.check(self._lib.rp_batch_solve_launch(self._h, float(gap_tol), int(max_iter), int(k)))
+
     def move_toward_feasibility(self):
         capi.check(self._lib.rp_batch_move_toward_feasibility(self._h))
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "rp_batch_step": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rp_batch_step_counted": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "rp_batch_solve": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
+    "rp_batch_solve_launch": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
     "rp_batch_move_toward_feasibility": (ctypes.c_int, [_vp]),
     "rp_batch_get_iters": (ctypes.c_int, [_vp, _vp, _vp]),
     "rp_batch_reduce": (ctypes.c_int, [_vp, ctypes.POINTER(Reduction)]),

@@ -463,6 +463,16 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
     return RP_OK;
 }
 
+int rp_batch_solve_launch(rp_batch *b, double gap_tol, int max_iter, int k)
+{
+    RP_NEED(b);
+    if (max_iter < 0 || max_iter > 1000000) return fail(RP_ERR_INVALID, "max_iter %d out of range (0..1000000)", max_iter);
+    if (k < 1 || k > 1000000) return fail(RP_ERR_INVALID, "steps per launch %d out of range (1..1000000)", k);
+    if (!(gap_tol == gap_tol)) return fail(RP_ERR_INVALID, "gap_tol is NaN");
+    RP_HIP(rp::launch_solve(b->view, b->params, k, gap_tol, max_iter, b->stream));
+    return RP_OK;
+}
+
 int rp_batch_move_toward_feasibility(rp_batch *b)
 {
     RP_NEED(b);

@@ -37,3 +37,38 @@ def batch_summary(batch, device=None, group=None):
     batch.reduce_device(out.data_ptr())
     batch.sync()          # the batch runs on its own stream; the collective runs on torch's
     return allreduce_summary(out, group)
+
+
+def solve_with_global_checks(launch, local_summary, n_total, max_iter, steps_per_check, group=None):
+    """Gated solve of a sharded batch with a GLOBAL convergence check ("RCCL all-reduce(max) of
+    per-GPU max ||r||^2 / max gap each check").
+
+    launch()        -- enqueue up to `steps_per_check` gated steps on this rank's shard (Batch.solve_launch)
+    local_summary() -- this rank's 4-double summary tensor (batch_summary's input: reduce_device into a tensor)
+    Every check all-reduces the 32-byte summary; the loop ends when every problem of every shard is converged or when
+    ceil(max_iter / steps_per_check) rounds have run (problems at their cap stop on their own).  Returns
+    (global summary tensor, checks made).  Nothing else crosses between ranks."""
+    if steps_per_check < 1:
+        raise ValueError("steps_per_check must be positive")
+    rounds = max(1, -(-max_iter // steps_per_check))
+    g = None
+    for check in range(1, rounds + 1):
+        launch()
+        g = allreduce_summary(local_summary(), group)
+        if float(g[2]) >= n_total:
+            return g, check
+    return g, rounds
+
+
+def batch_solve_with_global_checks(batch, n_total, gap_tol=1e-8, max_iter=200, steps_per_check=4, device=None, group=None):
+    """solve_with_global_checks for a rocket_path_amd.Batch shard (the device writes the summary straight into the tensor
+    that is all-reduced)."""
+    dev = device if device is not None else torch.device("cuda", batch.device)
+
+    def local():
+        out = torch.empty(4, dtype=torch.float64, device=dev)
+        batch.reduce_device(out.data_ptr())
+        batch.sync()
+        return out
+    return solve_with_global_checks(lambda: batch.solve_launch(gap_tol, max_iter, steps_per_check), local, n_total, max_iter,
+                                    steps_per_check, group)

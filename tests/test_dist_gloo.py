@@ -22,13 +22,13 @@ def _free_port():
     return p
 
 
-def _run_world(world, n_total):
+def _run_world(world, n_total, *extra):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(n_total)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(n_total)] + [str(x) for x in extra],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -89,3 +89,23 @@ def test_sharded_summary_equals_whole_batch(world, oracle):
     assert g[3] == float(total)
     assert g[2] == float(n_total)
     assert g[1] == gaps.max()
+
+
+def test_solve_with_global_checks_stops_every_rank_at_the_same_check(oracle):
+    # an all-reduce of the summary at every convergence check.  All ranks leave the loop at the same check -- the
+    # first one at which the GLOBAL converged count reaches n_total -- with the same global summary.
+    n_total, k = 301, 4
+    outs = _run_world(2, n_total, "polled", k)
+    assert outs[0]["global"] == outs[1]["global"] and outs[0]["checks"] == outs[1]["checks"]
+    p0, p1, p2 = problems.generate(12345, 0, n_total, problems.DIST_MONOTONE)
+    aos = oracle.batch_init_feasible(3, p0, p1, p2)
+    iters, total = oracle.batch_solve_gated(3, aos, 1e-8, 200)
+    assert outs[0]["global"][2] == float(n_total) and outs[0]["global"][3] == float(total)
+    assert outs[0]["checks"] == -(-int(iters.max()) // k)            # the slowest problem of the WHOLE batch decides
+    assert max(o["local_max_iters"] for o in outs) == int(iters.max())
+    # single process: plain loop
+    calls = []
+    g, checks = sharding.solve_with_global_checks(lambda: calls.append(1), lambda: torch.tensor([0.0, 0.0, 5.0, 9.0], dtype=torch.float64), 5, 200, 7)
+    assert checks == 1 and len(calls) == 1 and g.tolist() == [0.0, 0.0, 5.0, 9.0]
+    g, checks = sharding.solve_with_global_checks(lambda: calls.append(1), lambda: torch.tensor([0.0, 1.0, 4.0, 9.0], dtype=torch.float64), 5, 20, 7)
+    assert checks == 3                                                 # never converges: ceil(20 / 7) rounds, then stop

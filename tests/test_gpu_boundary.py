@@ -196,3 +196,45 @@ def test_single_process_sharded_bench_prints_the_bench_keys():
     assert line["config"]["newton_steps_per_pass"] == r["total_steps"] and line["config"]["converged"] == n
     assert line["config"]["max_gap"] < 1e-8 and line["value"] > 1e9
     assert len(line["per_device_ms_per_pass"]) == 1 and 0 < line["per_device_ms_per_pass"][0] <= line["ms_per_step"] * 1.001
+
+
+_GLOBAL_CHECK_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+torch.cuda.init()                    # torch's HIP runtime first (as in bench.py): the other order leaves torch without a device
+sys.path.insert(0, sys.argv[1])
+import rocket_path_amd as rp
+from rocket_path_amd import sharding
+n = 5000
+p0, p1, p2 = rp.problems.generate(12345, 0, n, rp.problems.DIST_MONOTONE)
+with rp.Batch(n) as a, rp.Batch(n) as b:
+    a.set_problems(p0, p1, p2)
+    b.set_problems(p0, p1, p2)
+    a.solve(1e-8, 200, 0)
+    g, checks = sharding.batch_solve_with_global_checks(b, n, 1e-8, 200, steps_per_check=4)
+    ia, sa = a.get_iters()
+    ib, sb = b.get_iters()
+    assert np.array_equal(a.get_state(), b.get_state()) and np.array_equal(ia, ib) and np.array_equal(sa, sb)
+    assert checks == -(-int(ia.max()) // 4), (checks, ia.max())
+    r = a.reduce()
+    assert g.tolist() == [r["max_residual_sq"], r["max_gap"], r["n_converged"], r["total_steps"]]
+    b.init_stuck()                   # cannot converge: the loop ends after ceil(max_iter / k) checks
+    g, checks = sharding.batch_solve_with_global_checks(b, n, 1e-8, 30, steps_per_check=8)
+    assert checks == 4 and float(g[2]) == 0.0 and np.all(b.get_iters()[0] == 30)
+    try:
+        b.solve_launch(1e-8, 200, 0)
+        raise SystemExit("k = 0 accepted")
+    except rp.RpError:
+        pass
+print("global checks ok")
+"""
+
+
+def test_solve_launch_and_the_global_check_loop_on_one_device():
+    # rp_batch_solve_launch = one launch of up to k gated steps; sharding.batch_solve_with_global_checks drives it with a
+    # summary (all-)reduce per check, the device writing into the torch tensor that is reduced -- world size 1 here, the
+    # N-rank algebra is covered on CPU with gloo.  Own process: torch must initialise its HIP runtime before the library does.
+    import sys
+    out = subprocess.run([sys.executable, "-c", _GLOBAL_CHECK_SCRIPT, ROOT], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "global checks ok" in out.stdout, out.stderr[-2000:]
