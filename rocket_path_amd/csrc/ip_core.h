@@ -112,6 +112,7 @@ template <typename T> struct KParams {
     T backtrack;    // 0.5
     T armijo;       // 0.01
     T c_floor;      // L * eps / 256: the shift applied to every c_i before it is inverted (see c_guard)
+    T x_floor;      // 2 L c_floor: the same shift on the product cm cp of an F3 constraint pair
     int max_bt;     // 100
     int stall_window;   // 0 = off; see rp_params.stall_window
     T sigma_try[2];     // mu_mode 1: centring parameters tried (ascending) before the reference's 1/mu_divisor; see newton_step
@@ -428,6 +429,10 @@ __device__ __forceinline__ void solve3(T a00, T a01, T a02, T a10, T a11, T a12,
 // cannot cancel c_i (values of a - L are multiples of ulp(L)/2 >> c_floor), and an exact zero
 // becomes the negative number of that size.  One add instead of a compare and two selects.
 template <typename T> __device__ __forceinline__ T c_guard(T c, T c_floor) { return c - c_floor; }
+// F3 inverts its constraints pairwise through x = cm cp (direction): there the shift rides on the product, x + 2 L c_floor, in
+// the multiply-add that forms it.  With cp -> 0 (cm -> -2L) that is cm (cp - c_floor) to first order, i.e. the same guarded
+// 1/cp = cm / x; the inactive partner's 1/cm = cp / x inherits a relative change c_floor / |cp|, which matters only below
+// |cp| ~ 1e-13 where its multiplier (~ p / 2L) has no influence on K or the right-hand side.
 
 // K dx = rhs for the arrow matrix K = [[a, b, c], [b, d, 0], [c, 0, e]] (K(t0,t1) is structurally
 // zero).  d and e are eliminated first when they pass the Bunch-Kaufman 1x1 pivot test
@@ -477,9 +482,9 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
             T cm[4], cp[4], x[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                cm[j] = c_guard(-e.a[j] - L, kp.c_floor);
-                cp[j] = c_guard(e.a[j] - L, kp.c_floor);
-                x[j] = cm[j] * cp[j];
+                cm[j] = -e.a[j] - L;
+                cp[j] = e.a[j] - L;
+                x[j] = fma_(cm[j], cp[j], kp.x_floor);      // the c_guard shift, applied to the pair's product (see c_guard)
             }
             const T x01 = x[0] * x[1], x23 = x[2] * x[3];
             const T iall = rcp_(x01 * x23);
@@ -792,6 +797,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 
     // -- backtrack until the residual decreases (onedpath_ip.cpp:932-945) --
     bool accepted = false;         // et = values at the point the loop broke on
+    T tl[SUMS ? NC : 1];           // gated kernels: the trial multipliers lam + s dl of the last evaluated trial
     int it = 0;
     bool frozen = false;           // the trial point has become bitwise x (and stays so: s only shrinks)
     for (; it < kp.max_bt; ++it) {
@@ -804,7 +810,9 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         diag.moving();
         T rn;
         if constexpr (SUMS) {
-            residual_sums<T, VARIANT, true>(et, lam, dl, s, L, c.X, c.Q1, c.Q2);      // overwritten by every trial: the accepted one stays
+#pragma unroll
+            for (int i = 0; i < NC; ++i) tl[i] = fma_(dl[i], s, lam[i]);              // kept: the accepted trial IS the update
+            residual_sums<T, VARIANT, false>(et, tl, dl, T(0), L, c.X, c.Q1, c.Q2);   // overwritten by every trial: the accepted one stays
             rn = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
         } else {
             rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
@@ -917,11 +925,17 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     }
 
     // -- take the step (onedpath_ip.cpp:949-952) --
-    v = fma_(dxv, s, v);
-    t0 = fma_(dx0, s, t0);
-    t1 = fma_(dx1, s, t1);
+    if (SUMS && accepted) {        // the accepted trial point and multipliers are the update, bit for bit
+        v = tv; t0 = tt0; t1 = tt1;
 #pragma unroll
-    for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
+        for (int i = 0; i < NC; ++i) lam[i] = tl[SUMS ? i : 0];
+    } else {
+        v = fma_(dxv, s, v);
+        t0 = fma_(dx0, s, t0);
+        t1 = fma_(dx1, s, t1);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
+    }
 
     if (!accepted) {                                   // the loop ran out of halvings: its last s was never evaluated
         accel_values(k, v, t0, t1, et);

@@ -54,6 +54,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
     kp.backtrack = (T)hp.backtrack;
     kp.armijo = (T)hp.armijo;
     kp.c_floor = (T)hp.accel_limit * (sizeof(T) == 8 ? (T)8.673617379884035e-19 : (T)4.656612873077393e-10);   // L * eps / 256
+    kp.x_floor = T(2) * kp.limit * kp.c_floor;
     kp.max_bt = hp.max_backtracks;
     kp.stall_window = hp.stall_window;
     kp.sigma_try[0] = (T)hp.mu_sigma_try[0];
