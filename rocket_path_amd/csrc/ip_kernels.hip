@@ -334,6 +334,8 @@ k_newton_counted(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T
 // floats), loads each field of all of them with one global_load_dwordx4 (a wave moves 1 KiB per instruction), steps
 // them one after the other and stores each mutable field with one global_store_dwordx4.  No prefetch registers:
 // the 14 x 16 B a lane holds for its problems are the latency cover (57 KiB in flight per resident block).
+// Loads and stores are NONTEMPORAL: every byte is touched once per launch, and keeping it out of the caches' way is
+// worth 7 % at k = 1 (same box, alternating runs: 4.66 -> 4.98 TB/s; k = 0: 4.79 -> 5.33; -DRP_STREAM_PLAIN for the A/B).
 // Covers floor(n / (256 PER)) full blocks; launch_steps hands the ragged remainder to k_newton_stream.
 template <typename S> struct Vec16;
 template <> struct Vec16<double> { using type = double __attribute__((ext_vector_type(2))); static constexpr int PER = 2; };
@@ -352,7 +354,11 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
     V f[NF];
 #pragma unroll
     for (int q = 0; q < NF; ++q)
+#ifndef RP_STREAM_PLAIN
+        if (!(ZV && (q == CB + 1 || q == CB + 4))) f[q] = __builtin_nontemporal_load(reinterpret_cast<const V *>(base + (size_t)q * stride + i));
+#else
         if (!(ZV && (q == CB + 1 || q == CB + 4))) f[q] = *reinterpret_cast<const V *>(base + (size_t)q * stride + i);
+#endif
 #pragma unroll
     for (int c = 0; c < PER; ++c) {
         T v = (T)f[0][c], t0 = (T)f[1][c], t1 = (T)f[2][c];
@@ -377,7 +383,11 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
         for (int q = 0; q < NC; ++q) f[3 + q][c] = (S)lam[q];
     }
 #pragma unroll
+#ifndef RP_STREAM_PLAIN
+    for (int q = 0; q < CB; ++q) __builtin_nontemporal_store(f[q], reinterpret_cast<V *>(base + (size_t)q * stride + i));
+#else
     for (int q = 0; q < CB; ++q) *reinterpret_cast<V *>(base + (size_t)q * stride + i) = f[q];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -398,6 +408,15 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
 // (positions nudged after it was computed) is merely a less effective schedule.
 constexpr int kTile = 512;
 constexpr int kBuckets = 64;
+
+// once-per-launch global accesses of the tiled kernels (tile staging in, results out)
+#if !defined(RP_STREAM_PLAIN) && !defined(RP_TILE_PLAIN)
+template <typename S> __device__ __forceinline__ S ld_once(const S *p) { return __builtin_nontemporal_load(p); }
+template <typename S> __device__ __forceinline__ void st_once(S *p, S v) { __builtin_nontemporal_store(v, p); }
+#else
+template <typename S> __device__ __forceinline__ S ld_once(const S *p) { return *p; }
+template <typename S> __device__ __forceinline__ void st_once(S *p, S v) { *p = v; }
+#endif
 
 template <typename T, int VARIANT>
 __global__ void __launch_bounds__(kBlock)
@@ -463,7 +482,7 @@ k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
     // -- stage the tile: field-major in LDS, every global access a full coalesced segment
 #pragma unroll
     for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kBlock) sm[f][j] = base[(size_t)f * stride + first + j];
+        for (int j = tid; j < count; j += kBlock) sm[f][j] = ld_once(base + (size_t)f * stride + first + j);
     if (GATED)
         for (int j = tid; j < count; j += kBlock) { s_it[j] = iters[first + j]; s_st[j] = status[first + j]; }
     // this thread's two scheduled problems: sorted chunks `wave` and `7 - wave`
@@ -517,7 +536,7 @@ k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
     // -- write the tile back: mutable fields and progress words
 #pragma unroll
     for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kBlock) base[(size_t)f * stride + first + j] = sm[f][j];
+        for (int j = tid; j < count; j += kBlock) st_once(base + (size_t)f * stride + first + j, sm[f][j]);
     if (GATED) {
         for (int j = tid; j < count; j += kBlock) { iters[first + j] = s_it[j]; status[first + j] = s_st[j]; }
         const unsigned long long open_mask = __ballot(open_any);
