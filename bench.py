@@ -303,7 +303,7 @@ def main():
     if not args.no_extras:
         # (a) one launch per Newton step: the HBM-streaming form of the same step (216 B really move per step).
         #     cold = every launch on a batch not touched since its init (state comes from HBM);
-        #     warm = the same 128 MiB batch stepped again and again (state stays in the 256 MiB Infinity Cache);
+        #     warm = the same 128 MiB batch stepped again and again (reported for completeness: with nontemporal accesses ~cold);
         #     probe = the same kernel with zero steps: its 16 loads + 11 stores per problem and nothing else,
         #             i.e. what this access pattern can reach on this box (the kernel's own ceiling).
         spare = batches[:min(len(batches), 20)]
@@ -368,7 +368,7 @@ def main():
                 "device_copy_16B_per_lane_GBps": moved(ms_copy), "kernel_vs_copy": ms_copy / ms_cold,
                 "note": "k = 0 launch of the same kernel (14 loads + 11 stores per problem, nothing else) and a torch device copy of "
                         "the same byte count, both cold, both timed in this run"},
-            "infinity_cache_resident_GBps": moved(ms_warm),
+            "same_batch_stepped_repeatedly_GBps": moved(ms_warm),      # nontemporal accesses: the 128 MiB state no longer lingers in the Infinity Cache
             "launches": len(spare)}
         # (b) configs[1]: 65,536 problems, exactly 50 steps each, one fused launch
         n2 = min(65536, count)

@@ -110,7 +110,7 @@ int need_aos(rp_batch *b)
 
 extern "C" {
 
-const char *rp_version(void) { return "rocket_path_amd 0.1 (gfx950)"; }
+const char *rp_version(void) { return "rocket_path_amd 0.2 (gfx950)"; }
 const char *rp_last_error(void) { return g_err; }
 
 const char *rp_status_string(int status)
