@@ -968,7 +968,7 @@ hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k,
 hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(kShards), 0, stream, b.counters);
+    // (the open-lane shards are not zeroed here: only the host-polled loop reads them, and launch_solve zeroes them itself)
     // Below ~2 tiles per CU slot the tiled kernel cannot fill the chip (one 256-thread block per
     // 512 problems): small batches take the plain one-problem-per-lane kernel.
     static const bool no_tiled = getenv("RP_NO_TILED") != nullptr;     // A/B switch for tuning
