@@ -773,6 +773,13 @@ def test_halving_counts_equal_the_oracles_step_by_step(oracle):
         assert tot_f > 3000                                   # the comparison is not vacuous: ~0.2 halvings per step
         assert np.array_equal(a.get_state(), b.get_state())   # the counted twin computes the very same steps
         assert np.array_equal(a.get_iters()[0], b.get_iters()[0])
+        # ... and keeps doing so through the post-convergence regime (memoised trial points, affine residual pieces, the
+        # closed-form tail of a feasibility loop stuck on x vs. its counted loop form): 30 more steps, still bit for bit
+        for s in range(30):
+            nf, nr = a.step_counted(1)
+            b.step(1)
+        assert nr.max() >= 40 and nf.max() == 100             # the regime was reached: ~50 residual halvings, stuck feasibility loops
+        assert np.array_equal(a.get_state(), b.get_state())
 
 
 @pytest.mark.parametrize("variant,dist,steps", [(rp.VARIANT_F3, rp.problems.DIST_NON_MONOTONE, 12), (rp.VARIANT_F3, rp.problems.DIST_REFERENCE_LIKE, 14),
