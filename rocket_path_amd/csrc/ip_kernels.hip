@@ -337,9 +337,12 @@ k_newton_counted(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T
 // Loads and stores are NONTEMPORAL: every byte is touched once per launch, and keeping it out of the caches' way is
 // worth 7 % at k = 1 (same box, alternating runs: 4.66 -> 4.98 TB/s; k = 0: 4.79 -> 5.33; -DRP_STREAM_PLAIN for the A/B).
 // Covers floor(n / (256 PER)) full blocks; launch_steps hands the ragged remainder to k_newton_stream.
-template <typename S> struct Vec16;
-template <> struct Vec16<double> { using type = double __attribute__((ext_vector_type(2))); static constexpr int PER = 2; };
-template <> struct Vec16<float> { using type = float __attribute__((ext_vector_type(4))); static constexpr int PER = 4; };
+// S = storage, T = arithmetic.  fp32 state with fp64 arithmetic takes 8 B per lane (two problems): four sequential fp64
+// problems per lane would leave the launch compute-bound with half the waves (measured at 1 Mi F4: 26 -> see DESIGN tuning log).
+template <typename S, typename T> struct Vec16;
+template <> struct Vec16<double, double> { using type = double __attribute__((ext_vector_type(2))); static constexpr int PER = 2; };
+template <> struct Vec16<float, float> { using type = float __attribute__((ext_vector_type(4))); static constexpr int PER = 4; };
+template <> struct Vec16<float, double> { using type = float __attribute__((ext_vector_type(2))); static constexpr int PER = 2; };
 
 template <typename S, typename T, int VARIANT, bool ZV>
 __global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
@@ -348,8 +351,8 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
     constexpr int NF = CB + 5;
-    constexpr int PER = Vec16<S>::PER;
-    using V = typename Vec16<S>::type;
+    constexpr int PER = Vec16<S, T>::PER;
+    using V = typename Vec16<S, T>::type;
     const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * PER;
     V f[NF];
 #pragma unroll
@@ -940,7 +943,7 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     // k <= 2: memory-bound.  Full blocks of 256 lanes x 16 B go through k_newton_stream16; the ragged remainder (and,
     // under RP_STREAM_SCALAR=1, everything: the A/B switch of the tuning log) through the 8-byte prefetching kernel.
     static const bool scalar_only = getenv("RP_STREAM_SCALAR") != nullptr;
-    const size_t per_block = (size_t)kBlock * (16 / storage_size(b.dtype));
+    const size_t per_block = (size_t)kBlock * (b.dtype == 1 ? 4 : 2);      // problems per lane: Vec16<S, T>::PER
     const size_t nfull = (scalar_only || grid_env || k > 2) ? 0 : b.n / per_block * per_block;      // k >= 3 on a small batch: one problem per lane fills more SIMDs
     if (nfull > 0)
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton_stream16<S, T, V, Z>), dim3((unsigned)(nfull / per_block)), dim3(kBlock), 0, stream,
