@@ -238,3 +238,28 @@ def test_solve_launch_and_the_global_check_loop_on_one_device():
     import sys
     out = subprocess.run([sys.executable, "-c", _GLOBAL_CHECK_SCRIPT, ROOT], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "global checks ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shards", [3, 8])
+def test_logical_shards_on_one_device_equal_the_whole_batch(shards):
+    # the sharded path checked on ONE GPU by running the S shards of a batch one after the other and
+    # reducing their summaries as the collective would (MAX, MAX, SUM, SUM): states, counts and summary must be those of the
+    # unsharded batch -- no step looks beyond its own problem, so where the shard boundaries fall cannot matter.
+    n = 300_001                                    # ragged: shard sizes differ by one
+    p0, p1, p2 = rp.problems.generate(12345, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as whole:
+        whole.set_problems(p0, p1, p2)
+        whole.solve(1e-8, 200, 0)
+        st, (it, status), r = whole.get_state(), whole.get_iters(), whole.reduce()
+    g = [0.0, -np.inf, 0.0, 0.0]
+    for s in range(shards):
+        first, count = rp.problems.shard_range(n, s, shards)
+        q0, q1, q2 = rp.problems.generate(12345, first, count, rp.problems.DIST_MONOTONE)     # the shard generates its own slice
+        with rp.Batch(count) as b:
+            b.set_problems(q0, q1, q2)
+            b.solve(1e-8, 200, 0)
+            assert np.array_equal(b.get_state(), st[first:first + count])
+            assert np.array_equal(b.get_iters()[0], it[first:first + count])
+            rs = b.reduce()
+        g = [max(g[0], rs["max_residual_sq"]), max(g[1], rs["max_gap"]), g[2] + rs["n_converged"], g[3] + rs["total_steps"]]
+    assert g == [r["max_residual_sq"], r["max_gap"], r["n_converged"], r["total_steps"]]
