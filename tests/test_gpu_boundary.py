@@ -263,3 +263,32 @@ def test_logical_shards_on_one_device_equal_the_whole_batch(shards):
             rs = b.reduce()
         g = [max(g[0], rs["max_residual_sq"]), max(g[1], rs["max_gap"]), g[2] + rs["n_converged"], g[3] + rs["total_steps"]]
     assert g == [r["max_residual_sq"], r["max_gap"], r["n_converged"], r["total_steps"]]
+
+
+def test_two_rank_bench_rehearsal_on_one_device_covers_the_whole_batch():
+    # bench.py's N-rank code path with the GPU kernels doing the work: two processes, both on device 0, gloo for the
+    # collectives (RCCL refuses two ranks on one GPU) -- each rank generates and solves ITS contiguous shard of the 2 x 262,144
+    # problems; the all-reduced summary must be that of the unsharded 524,288-problem batch.  (Not a benchmark result.)
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    per = 262144
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2",
+                          "--warmup", "1", "--problems-per-gpu", str(per), "--no-extras"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "REHEARSAL" in line["data"] and line["cpu_baseline"] is None
+    assert line["config"]["problems_total"] == 2 * per and line["config"]["converged_fraction"] == 1.0
+    p0, p1, p2 = rp.problems.generate(12345, 0, 2 * per, rp.problems.DIST_MONOTONE)
+    with rp.Batch(2 * per) as b:
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 200, 0)
+        r = b.reduce()
+    g = line["config"]["final_summary"]
+    assert g["n_converged"] == 2 * per and g["total_steps"] == r["total_steps"]
+    assert g["max_gap"] == r["max_gap"] and g["max_residual_sq"] == r["max_residual_sq"]
