@@ -22,20 +22,27 @@
 //     S lam g      = (lp - lm) grad a          S lam H = (lp - lm) hess a
 //     S (lam/c) gg = (lm/cm + lp/cp) grad a grad a^T
 //     S g p/c      = p (1/cp - 1/cm) grad a
-// and 1/cm, 1/cp come from ONE reciprocal of cm*cp.
+// and all eight 1/cm_j, 1/cp_j come from ONE reciprocal (of the product of the four cm_j cp_j).
 //
 // Arithmetic notes (tolerance of the path is 1e-10 relative, not bitwise):
 //  * compiled with -ffp-contract=off; every fused multiply-add below is written out, so the
-//    same expression gives the same bits wherever it is inlined.  That is what makes the two
-//    memoisations exact: a trial point that is bitwise the current point re-uses the current
-//    point's evaluation (the reference recomputes the same numbers), and the evaluation at
-//    the accepted trial point is carried into the next step instead of being recomputed.
-//  * the kernel is fp64-ALU bound, and an IEEE fp64 division costs 11 instructions on gfx950
-//    (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup).  Every division on the path is a
-//    reciprocal: v_rcp_f64 + two Newton iterations (5 instructions, <= 1-2 ulp), shared where
-//    the reference divides repeatedly by the same number (it divides by t about 20 times per
-//    constraint sweep, onedpath_ip.cpp:385-391, 404-410).  Define RP_EXACT_DIV to build with
-//    correctly rounded divisions instead (A/B builds for parity checks).
+//    same expression gives the same bits wherever it is inlined.  That is what makes the
+//    re-uses exact: a trial point that is bitwise the current point re-uses the current
+//    point's evaluation (the reference recomputes the same numbers; MEMO), the evaluation at
+//    the accepted trial point is carried into the next step instead of being recomputed, and in
+//    the gated kernels so are the sums its residual test was made of (residual_sums).
+//  * the kernels are fp64-ALU bound (the vector ALU issues ~97 % of the cycles), so the currency
+//    is instructions: ~420 per Newton step.  An IEEE fp64 division costs 11 of them on gfx950
+//    (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup); every division on the path is a
+//    reciprocal, v_rcp_f64 + two Newton iterations (5 instructions, <= 1-2 ulp, the issue time
+//    of ~7 multiplications), and reciprocals are batched: one for the two durations of a trial
+//    point (the reference divides by t about 20 times per constraint sweep,
+//    onedpath_ip.cpp:385-391, 404-410), one for all constraints, one for the two arrow pivots,
+//    one for the boundary fraction -- 5 per step where the first version of this file had 19.
+//    Define RP_EXACT_DIV to build with correctly rounded divisions instead (A/B builds).
+//  * template switches of newton_step: MEMO (fixed-step kernels: exact memoisation for the
+//    reference's post-convergence regime), AFFINE (with MEMO: that regime's residual loop on affine
+//    pieces), MU (rp_params.mu_mode), a bookkeeping hook (halving counts for rp_batch_step_counted).
 #pragma once
 
 #include <hip/hip_runtime.h>
