@@ -284,8 +284,8 @@ def main():
             "traffic": traffic, "traffic_source": traffic_src,
             "note": "flop actually executed by the timed kernel (SQ counters of the same kernel on identical problems, per lane-step); "
                     "idle lane-steps of the gated solve (~5 %) are not counted; traffic = HBM bytes per launch from FETCH_SIZE (x2, "
-                    "calibrated) + WRITE_SIZE: each state crosses HBM once per solve.  A step got cheaper in round 2 (609 -> 537 flop in "
-                    "the fixed-step kernels, 453 in the gated one, which carries its residual sums), so this fraction FALLS while steps/s "
+                    "calibrated) + WRITE_SIZE: each state crosses HBM once per solve.  A step got cheaper in round 2 (609 -> 533 flop in "
+                    "the fixed-step kernels, 431 in the gated one, which carries its residual sums), so this fraction FALLS while steps/s "
                     "rise: the vector ALU is issue-saturated either way (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.32 x 3 resident waves)",
             "same_rate_at_round1_operation_count": {"flop_per_newton_step": 609.4, "achieved": 609.4 * steps_per_launch / (kernel_ms * 1e-3) / 1e12,
                                                     "frac": 609.4 * steps_per_launch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,

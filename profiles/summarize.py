@@ -22,7 +22,8 @@ PROBE_STEPS = 12      # profiles/pmc_probe.py
 
 
 def one(d, pat):
-    return glob.glob(os.path.join(d, "*", pat))[0]
+    """The newest match: gpurun merges a call's files into gpurun_out/ without removing an earlier call's."""
+    return max(glob.glob(os.path.join(d, "*", pat)), key=os.path.getmtime)
 
 
 shutil.copy(one(stats_dir, "*_kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_kernel_stats.csv" % tag))

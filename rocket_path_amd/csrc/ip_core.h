@@ -32,7 +32,7 @@
 //    the accepted trial point is carried into the next step instead of being recomputed, and in
 //    the gated kernels so are the sums its residual test was made of (residual_sums).
 //  * the kernels are fp64-ALU bound (the vector ALU issues ~97 % of the cycles), so the currency
-//    is instructions: ~420 per Newton step.  An IEEE fp64 division costs 11 of them on gfx950
+//    is instructions: 370-440 per Newton step.  An IEEE fp64 division costs 11 of them on gfx950
 //    (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup); every division on the path is a
 //    reciprocal, v_rcp_f64 + two Newton iterations (5 instructions, <= 1-2 ulp, the issue time
 //    of ~7 multiplications), and reciprocals are batched: one for the two durations of a trial
