@@ -247,6 +247,16 @@ def main():
     if flop_per_step is None:
         flop_per_step, flop_src = 560.0, "estimate (no profiles/%s_sq_counters.json)" % PROFILE_TAG
     tflops = flop_per_step * steps_per_launch / (kernel_ms * 1e-3) / 1e12
+    winsts, winsts_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_valu_wave_insts_per_gated_launch")
+    VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4      # G wave-instructions/s at the fp64 rate
+    valu_issue = None
+    if winsts is not None and abs(count - N_PER_GPU) == 0:
+        valu_issue = {"achieved": winsts / (kernel_ms * 1e-3) / 1e9, "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instructions/s",
+                      "frac": winsts / (kernel_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_G,
+                      "valu_wave_instructions_per_launch": winsts, "source": winsts_src,
+                      "note": "SQ_INSTS_VALU of this launch (1,048,576 problems, idle lanes included) over this run's launch time; every "
+                              "instruction priced at the fp64 issue cost and the peak at the 2.4 GHz the chip does not hold under this load "
+                              "(~2.0 GHz): the remainder is clock, not stalls"}
     line = {
         "metric": "interior-point Newton steps/sec (whole node) + achieved HBM GB/s, 1M-problem batch",
         "value": steps_all / elapsed,
@@ -287,6 +297,9 @@ def main():
                     "calibrated) + WRITE_SIZE: each state crosses HBM once per solve.  A step got cheaper in round 2 (609 -> 533 flop in "
                     "the fixed-step kernels, 431 in the gated one, which carries its residual sums), so this fraction FALLS while steps/s "
                     "rise: the vector ALU is issue-saturated either way (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.32 x 3 resident waves)",
+            # the roof in the unit that binds: wave-level VALU instructions issued per second against one fp64-rate instruction
+            # per 4 cycles per SIMD (256 CU x 4 SIMD x 2.4 GHz / 4)
+            "valu_issue": valu_issue,
             "same_rate_at_round1_operation_count": {"flop_per_newton_step": 609.4, "achieved": 609.4 * steps_per_launch / (kernel_ms * 1e-3) / 1e12,
                                                     "frac": 609.4 * steps_per_launch / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                                     "note": "what the round-1 kernel would have had to sustain for this step rate (for comparison across rounds only)"},

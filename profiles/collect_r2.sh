@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-2 profile collection (GPU box, from the repo root):  bash profiles/collect_r2.sh
+# (gpurun merges outputs into the local gpurun_out/ without deleting an earlier call's files: profiles/summarize.py takes the newest.)
 # rocprofv3 gets the program directly after `--` (no env/bash hop); counters and traces in separate passes.
 set -e
 export TMPDIR=/tmp

@@ -79,7 +79,7 @@ json.dump(out, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag),
 
 sq = {}
 for d in sq_dirs:
-    for k, cs in counters(d).items():
+    for k, cs in counters(d, grid=N // 2).items():      # the 1 Mi-problem launches: 524,288 work-items in every Newton kernel of the probe
         name = short(k)
         if name.startswith(("k_newton", "k_solve")):
             sq.setdefault(name, {}).update(cs)
@@ -121,6 +121,9 @@ if "SQ_INSTS_VALU_FMA_F64" in ident:
         ident["valu_insts_per_lane_step"] = 64.0 * ident["SQ_INSTS_VALU"] / ls
     sq["k_solve_tiled<double, double, 3, true, false, true> on identical problems"] = ident
     top["_flop_per_gated_newton_step"] = ident["flop_f64_per_lane_step"]
+gated_real = sq.get("k_solve_tiled<double, double, 3, true, false, true>", {})
+if "SQ_INSTS_VALU" in gated_real:
+    top["_valu_wave_insts_per_gated_launch"] = gated_real["SQ_INSTS_VALU"]      # the benchmark's launch itself (idle lanes included)
 sq.update(top)
 json.dump({"_method": "rocprofv3 --pmc <SQ counters, <= 8 per pass> -- python3 profiles/pmc_probe.py (1 Mi problems: 12 fused ungated steps "
                       "of F3 f64 / F4 f32 / F4 f32-state, then the fused gated F3 solve and one k = 1 launch); SQ_WAVE_CYCLES / "
