@@ -9,7 +9,7 @@
 // algorithmic traffic of SURVEY.md 8d; the kernels instantiated for zero end velocities read 14.
 //
 // Launch shapes, all sharing the per-lane step of ip_core.h, all with 256-thread blocks:
-//   k_solve_tiled      the fused gated solve (the benchmark's kernel; 130 VGPRs, 3 waves per SIMD) and, ungated,
+//   k_solve_tiled      the fused gated solve (the benchmark's kernel; 140 VGPRs, 3 waves per SIMD) and, ungated,
 //                      k >= 3 steps on large batches: one 512-problem tile per block, staged in LDS and
 //                      scheduled by expected step count
 //   k_newton_stream16  k <= 2 ungated steps, the HBM-streaming form: 16 B per lane (two doubles / four floats =
