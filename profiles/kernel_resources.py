@@ -27,7 +27,7 @@ demangle = subprocess.run(["c++filt"] + [x["name"] for x in rows], capture_outpu
 print("%-62s %5s %5s %7s %6s %4s" % ("kernel", "VGPR", "spill", "scratch", "LDS", "occ"))
 for x, d in sorted(zip(rows, demangle), key=lambda t: t[1]):
     d = d.replace("void rp::(anonymous namespace)::", "").split("(")[0]
-    if not d.startswith(("k_newton", "k_solve")):
+    if not d.startswith(("k_newton", "k_solve", "k_steps")):
         continue
     print("%-62s %5d %5d %7d %6d %4d" % (d, x.get("VGPRs", -1), x.get("VGPRs Spill", 0), x.get("ScratchSize [bytes/lane]", 0),
                                         x.get("LDS Size [bytes/block]", 0), x.get("Occupancy [waves/SIMD]", -1)))

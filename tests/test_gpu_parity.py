@@ -806,3 +806,21 @@ def test_halving_counts_on_the_other_distributions_and_f4(oracle, variant, dist,
     # F4 trajectories are chaotic (rounding-level differences grow ~10x every few steps; parity of its states
     # is pinned per step from identical states, test_f4_fp64_single_steps): after 10 steps only the decisions are compared tightly
     assert serr(st[:, :3], aos[:, :3]) < (TOL if variant == rp.VARIANT_F3 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [rp.DTYPE_F64, rp.DTYPE_F32_STATE, rp.DTYPE_F32])
+def test_f4_regrouped_fixed_steps_equal_single_steps_bitwise(dtype):
+    # F4's long fixed-step runs on large batches go through k_steps_regrouped (problems re-sorted by line-search cost every four
+    # steps, chunks pulled from a queue): which lane steps a problem, and when, must not change a bit of its result
+    n = 512 * 512 + 77
+    p0, p1, p2 = rp.problems.generate(2026, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n, rp.VARIANT_F4, dtype) as a, rp.Batch(n, rp.VARIANT_F4, dtype) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0, p1, p2)
+        a.step(14)                       # regrouped kernel: 4 + 4 + 4 + 2 steps
+        for _ in range(14):
+            b.step(1)                    # streaming kernel
+        sa, sb = a.get_state(), b.get_state()
+        assert np.all(np.isfinite(sa))
+        assert np.array_equal(sa, sb)
+        assert np.all(a.get_iters()[0] == 14)

@@ -39,5 +39,5 @@ def test_tiled_kernels_fit_three_waves_without_scratch():
         assert 3 * v["LDS Size [bytes/block]"] <= 160 * 1024, (k, v)
     # nothing on the Newton path may spill in its default build
     for k, v in usage.items():
-        if "k_newton" in k or "k_solve_tiled" in k:
+        if "k_newton" in k or "k_solve_tiled" in k or "k_steps_regrouped" in k:
             assert v.get("VGPRs Spill", 0) == 0, (k, v)
