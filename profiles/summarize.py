@@ -73,6 +73,8 @@ alias("k_solve_tiled_f3_f64", "k_solve_tiled<double, double, 3, true",
 alias("k_newton_stream16_f3_f64", "k_newton_stream16<double, double, 3, true", "14x8 B read + 11x8 B written per problem = 117.4 + 92.3 MB")
 alias("k_newton_stream16_f4_f32", "k_newton_stream16<float, float, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
 alias("k_newton_stream16_f4_f32state", "k_newton_stream16<float, double, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
+alias("k_steps_regrouped_f4_f32", "k_steps_regrouped<float, float, 4", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per 50-step launch")
+alias("k_steps_regrouped_f4_f32state", "k_steps_regrouped<float, double, 4", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per 50-step launch")
 alias("k_solve_tiled_f4_f32", "k_solve_tiled<float, float, 4, false", "(10x4 + 2) B read + 7x4 B written per problem = 44.0 + 29.4 MB per 50-step launch")
 alias("k_solve_tiled_f4_f32state", "k_solve_tiled<float, double, 4, false", "(10x4 + 2) B read + 7x4 B written per problem = 44.0 + 29.4 MB per 50-step launch")
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag), "w"), indent=1)

@@ -16,6 +16,7 @@
 //                      that many consecutive problems per lane), one global_load/store_dwordx4 per field
 //   k_newton_stream    the same with one problem per lane and a register prefetch: ragged remainders, small
 //                      batches with k >= 3 (more waves than the 16-byte form), mu_mode 1
+//   k_steps_regrouped  F4's long fixed-step runs (k >= 20) on large batches: tiles re-sorted by line-search cost every 4 steps
 //   k_newton           one problem per lane in batch order, gated: small batches, host-polled gated loops, mu_mode 1
 // Problems are independent and nothing is re-read, so there is no L2 locality to arrange: the
 // plain blockIdx -> problem-range map is XCD-neutral (blocks are dealt round-robin over the 8 XCDs).
@@ -534,7 +535,9 @@ k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
             int it = GATED ? s_it[j] : 0;
             uint32_t st = GATED ? s_st[j] : 0u;
             bool still_open = false;
-            run_lane<T, VARIANT, GATED, STALL, Prob<T, ZV>, S>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+            // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
+            // its stalled problems), so all its fixed-step kernels use it and agree bit for bit; F3's tiled kernel would spill
+            run_lane<T, VARIANT, GATED, STALL, Prob<T, ZV>, S, (VARIANT == 4)>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
             open_any = open_any || still_open;
             sm[0][j] = (S)v;
             sm[1][j] = (S)t0;

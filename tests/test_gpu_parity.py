@@ -817,10 +817,14 @@ def test_f4_regrouped_fixed_steps_equal_single_steps_bitwise(dtype):
     with rp.Batch(n, rp.VARIANT_F4, dtype) as a, rp.Batch(n, rp.VARIANT_F4, dtype) as b:
         a.set_problems(p0, p1, p2)
         b.set_problems(p0, p1, p2)
-        a.step(14)                       # regrouped kernel: 4 + 4 + 4 + 2 steps
+        a.step(14)                       # tiled kernel (k < 20)
         for _ in range(14):
             b.step(1)                    # streaming kernel
         sa, sb = a.get_state(), b.get_state()
         assert np.all(np.isfinite(sa))
         assert np.array_equal(sa, sb)
-        assert np.all(a.get_iters()[0] == 14)
+        a.step(22)                       # regrouped kernel: 4 + 4 + 4 + 4 + 4 + 2 steps
+        for _ in range(22):
+            b.step(1)
+        assert np.array_equal(a.get_state(), b.get_state())
+        assert np.all(a.get_iters()[0] == 36)
