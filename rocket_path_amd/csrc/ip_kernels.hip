@@ -420,7 +420,12 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
 // together.  Idle lane-steps drop from 19 % to 5 % (2.7 % with a perfect predictor).  Which lane solves
 // which problem changes nothing in any problem's result (lanes never interact); a stale order
 // (positions nudged after it was computed) is merely a less effective schedule.
-constexpr int kTile = 512;
+#ifndef RP_TILE
+#define RP_TILE 512      // problems per tile of the tiled kernels; their blocks have RP_TILE / 2 threads (each wave two 64-problem chunks)
+#endif
+constexpr int kTile = RP_TILE;
+constexpr int kTileThreads = kTile / 2;
+constexpr size_t kTiledMin = 262144;      // below this many problems the tiled kernels cannot fill the chip
 constexpr int kBuckets = 64;
 
 // once-per-launch global accesses of the tiled kernels (tile staging in, results out)
@@ -433,11 +438,11 @@ template <typename S> __device__ __forceinline__ void st_once(S *p, S v) { *p = 
 #endif
 
 template <typename T, int VARIANT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kTileThreads)
 k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__restrict__ order)
 {
     constexpr int CB = 3 + CMap<VARIANT>::NC;
-    constexpr int PER = kTile / kBlock;
+    constexpr int PER = kTile / kTileThreads;
     __shared__ unsigned s_hist[kBuckets], s_start[kBuckets], s_fill[kBuckets];
     const int tid = threadIdx.x;
     const size_t first = (size_t)blockIdx.x * kTile;
@@ -447,7 +452,7 @@ k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__r
     int key[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const int j = tid + q * kBlock;
+        const int j = tid + q * kTileThreads;
         key[q] = -1;
         if (j < count) {
             const T p0 = base[(size_t)(CB + 0) * stride + first + j], p1 = base[(size_t)(CB + 2) * stride + first + j];
@@ -469,7 +474,7 @@ k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__r
     for (int q = 0; q < PER; ++q) {
         if (key[q] >= 0) {
             const unsigned pos = s_start[key[q]] + atomicAdd(&s_fill[key[q]], 1u);
-            order[first + pos] = (uint16_t)(tid + q * kBlock);      // tile-local index
+            order[first + pos] = (uint16_t)(tid + q * kTileThreads);      // tile-local index
         }
     }
 }
@@ -478,7 +483,7 @@ k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__r
 // staging (for k >= 3 the arithmetic dominates, and this is the form that fits three waves per SIMD).
 // Every instantiation fits 168 VGPRs without scratch (profiles/kernel_resources.py; any scratch makes the launch time erratic).
 template <typename S, typename T, int VARIANT, bool GATED, bool STALL, bool ZV>
-__global__ void __launch_bounds__(kBlock, RP_TILED_WAVES)
+__global__ void __launch_bounds__(kTileThreads, RP_TILED_WAVES)
 k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
               const uint16_t *__restrict__ order)
@@ -496,9 +501,9 @@ k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
     // -- stage the tile: field-major in LDS, every global access a full coalesced segment
 #pragma unroll
     for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kBlock) sm[f][j] = ld_once(base + (size_t)f * stride + first + j);
+        for (int j = tid; j < count; j += kTileThreads) sm[f][j] = ld_once(base + (size_t)f * stride + first + j);
     if (GATED)
-        for (int j = tid; j < count; j += kBlock) { s_it[j] = iters[first + j]; s_st[j] = status[first + j]; }
+        for (int j = tid; j < count; j += kTileThreads) { s_it[j] = iters[first + j]; s_st[j] = status[first + j]; }
     // this thread's two scheduled problems: sorted chunks `wave` and `7 - wave`
     const int wave = tid >> 6, lane = tid & 63;
     int mine[2];
@@ -552,13 +557,13 @@ k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
     // -- write the tile back: mutable fields and progress words
 #pragma unroll
     for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kBlock) st_once(base + (size_t)f * stride + first + j, sm[f][j]);
+        for (int j = tid; j < count; j += kTileThreads) st_once(base + (size_t)f * stride + first + j, sm[f][j]);
     if (GATED) {
-        for (int j = tid; j < count; j += kBlock) { iters[first + j] = s_it[j]; status[first + j] = s_st[j]; }
+        for (int j = tid; j < count; j += kTileThreads) { iters[first + j] = s_it[j]; status[first + j] = s_st[j]; }
         const unsigned long long open_mask = __ballot(open_any);
         const int steps_wave = wave_sum<int>(steps_here);
         if (lane == 0) {
-            const unsigned shard = (blockIdx.x * (kBlock / 64) + wave) & (kShards - 1);
+            const unsigned shard = (blockIdx.x * (kTileThreads / 64) + wave) & (kShards - 1);
             if (open_mask) atomicAdd(&counters[shard], (unsigned long long)__popcll(open_mask));
             if (steps_wave) atomicAdd(&counters[kShards + shard], (unsigned long long)steps_wave);
         }
@@ -577,7 +582,7 @@ k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
 // other three drain the cheap chunks.  State stays in LDS between regroupings; which lane steps a problem changes nothing in
 // its result (bit-identical to the other kernels: tests).
 template <typename S, typename T, int VARIANT, bool ZV>
-__global__ void __launch_bounds__(kBlock, RP_TILED_WAVES)
+__global__ void __launch_bounds__(kTileThreads, RP_TILED_WAVES)
 k_steps_regrouped(S *__restrict__ base, size_t stride, size_t n, int k, int every, KParams<T> kp)
 {
     constexpr int NC = CMap<VARIANT>::NC;
@@ -595,8 +600,8 @@ k_steps_regrouped(S *__restrict__ base, size_t stride, size_t n, int k, int ever
     const int count = (n - first < (size_t)kTile) ? (int)(n - first) : kTile;
 #pragma unroll
     for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kBlock) sm[f][j] = ld_once(base + (size_t)f * stride + first + j);
-    for (int j = tid; j < count; j += kBlock) {
+        for (int j = tid; j < count; j += kTileThreads) sm[f][j] = ld_once(base + (size_t)f * stride + first + j);
+    for (int j = tid; j < count; j += kTileThreads) {
         const S *g = base + first + j;
         const T q0 = (T)g[(size_t)(CB + 0) * stride], q1 = (T)g[(size_t)(CB + 2) * stride], q2 = (T)g[(size_t)(CB + 3) * stride];
         s_dx[0][j] = q1 - q0;
@@ -653,14 +658,14 @@ k_steps_regrouped(S *__restrict__ base, size_t stride, size_t n, int k, int ever
         if (done + every < k) {      // counting sort of the tile's problems by bucket (as k_order_tiles)
             if (tid < kBuckets) { s_hist[tid] = 0; s_fill[tid] = 0; }
             __syncthreads();
-            for (int j = tid; j < count; j += kBlock) atomicAdd(&s_hist[s_key[j]], 1u);
+            for (int j = tid; j < count; j += kTileThreads) atomicAdd(&s_hist[s_key[j]], 1u);
             __syncthreads();
             if (tid == 0) {
                 unsigned acc = 0;
                 for (int b = 0; b < kBuckets; ++b) { s_start[b] = acc; acc += s_hist[b]; }
             }
             __syncthreads();
-            for (int j = tid; j < count; j += kBlock) {
+            for (int j = tid; j < count; j += kTileThreads) {
                 const unsigned pos = s_start[s_key[j]] + atomicAdd(&s_fill[s_key[j]], 1u);
                 s_perm[pos] = (uint16_t)j;
             }
@@ -669,7 +674,7 @@ k_steps_regrouped(S *__restrict__ base, size_t stride, size_t n, int k, int ever
     }
 #pragma unroll
     for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kBlock) st_once(base + (size_t)f * stride + first + j, sm[f][j]);
+        for (int j = tid; j < count; j += kTileThreads) st_once(base + (size_t)f * stride + first + j, sm[f][j]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1052,16 +1057,16 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     // the second register set of the prefetch only costs occupancy, so k >= 3 on a batch large enough to fill the
     // chip with 512-problem tiles runs the tiled kernel, ungated (168 VGPRs with zero end velocities: 3 waves per SIMD).
     static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override: forces the streaming kernel
-    if (k >= 3 && !grid_env && b.n >= (size_t)kTile * 512) {
+    if (k >= 3 && !grid_env && b.n >= kTiledMin) {
         const unsigned tiles = (unsigned)((b.n + kTile - 1) / kTile);
         static const bool no_regroup = getenv("RP_NO_REGROUP") != nullptr;      // A/B switch for tuning
         static const int every = getenv("RP_REGROUP_EVERY") ? atoi(getenv("RP_REGROUP_EVERY")) : 4;      // tuning
         if (b.variant == 4 && k >= 20 && !no_regroup && every >= 1) {      // F4's long fixed-step runs: see k_steps_regrouped
-            RP_DISPATCH_Z(b, if constexpr (V == 4) hipLaunchKernelGGL((k_steps_regrouped<S, T, 4, Z>), dim3(tiles), dim3(kBlock), 0, stream,
+            RP_DISPATCH_Z(b, if constexpr (V == 4) hipLaunchKernelGGL((k_steps_regrouped<S, T, 4, Z>), dim3(tiles), dim3(kTileThreads), 0, stream,
                                                                       (S *)b.base, b.stride, b.n, k, every, make_kparams<T>(hp, 4)));
             return hipGetLastError();
         }
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, false, false, Z>), dim3(tiles), dim3(kBlock), 0, stream,
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, false, false, Z>), dim3(tiles), dim3(kTileThreads), 0, stream,
                                              (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), T(0), 0,
                                              (int32_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr,
                                              (const uint16_t *)b.order));
@@ -1108,7 +1113,7 @@ hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double g
                                                  (T)gap_tol, max_iter, b.iters, b.status, b.counters));
         return hipGetLastError();
     }
-    if (no_tiled || b.n < (size_t)kTile * 512) {
+    if (no_tiled || b.n < kTiledMin) {
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
                                              (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
                                              (T)gap_tol, max_iter, b.iters, b.status, b.counters));
@@ -1116,11 +1121,11 @@ hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double g
     }
     const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
     if (hp.stall_window > 0)
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, true, true, Z>), dim3(grid), dim3(kBlock), 0, stream,
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, true, true, Z>), dim3(grid), dim3(kTileThreads), 0, stream,
                                              (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
                                              (T)gap_tol, max_iter, b.iters, b.status, b.counters, (const uint16_t *)b.order));
     else
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, true, false, Z>), dim3(grid), dim3(kBlock), 0, stream,
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, true, false, Z>), dim3(grid), dim3(kTileThreads), 0, stream,
                                              (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
                                              (T)gap_tol, max_iter, b.iters, b.status, b.counters, (const uint16_t *)b.order));
     return hipGetLastError();
@@ -1130,7 +1135,7 @@ hipError_t launch_order(const BatchView &b, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_order_tiles<S, V>), dim3(grid), dim3(kBlock), 0, stream,
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_order_tiles<S, V>), dim3(grid), dim3(kTileThreads), 0, stream,
                                        (const S *)b.base, b.stride, b.n, b.order));
     return hipGetLastError();
 }
