@@ -184,10 +184,16 @@ RP_API int rp_batch_stream(rp_batch *b, void **stream);
 /* HIP events on the batch's own stream: record slot 0..7, elapsed between two recorded slots. */
 RP_API int rp_batch_event_record(rp_batch *b, int slot);
 RP_API int rp_batch_event_elapsed_ms(rp_batch *b, int slot_start, int slot_stop, float *ms);
-/* Device pointer of one SoA field (0..15 / 0..11) for callers that manage their own copies.  Asking for an
- * end-velocity field (vel0X / vel2X) makes the batch assume they may become non-zero (general kernels) until the
- * next init / set_problems / set_state. */
+/* Device pointer of one SoA field (0..15 / 0..11) for callers that manage their own copies.  Elements are in BATCH
+ * order: the batch keeps its problems sorted for the gated solve (set_problems / set_state decide the order), problem i's
+ * element is ptr[slot_of_problem[i]] with the map of rp_batch_slot_map.  Asking for an end-velocity field
+ * (vel0X / vel2X) makes the batch assume they may become non-zero (general kernels) until the next init /
+ * set_problems / set_state. */
 RP_API int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr);
+/* slot_of_problem[i] = position of problem i inside the batch's field arrays (n words; the identity after
+ * init_default / init_stuck).  Every other entry point takes and returns problem order; only rp_batch_field_ptr
+ * exposes batch order.  Synchronous. */
+RP_API int rp_batch_slot_map(rp_batch *b, uint32_t *slot_of_problem);
 
 #ifdef __cplusplus
 }

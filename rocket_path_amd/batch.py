@@ -179,6 +179,13 @@ class Batch:
         return ms.value
 
     def field_ptr(self, field):
+        """Device address of one field; its elements are in BATCH order (see slot_map)."""
         p = ctypes.c_void_p()
         capi.check(self._lib.rp_batch_field_ptr(self._h, field, ctypes.byref(p)))
         return p.value
+
+    def slot_map(self):
+        """slot_of_problem[i]: where problem i lies inside the batch's field arrays."""
+        out = np.empty(self.n, dtype=np.uint32)
+        capi.check(self._lib.rp_batch_slot_map(self._h, out.ctypes.data))
+        return out

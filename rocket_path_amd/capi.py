@@ -78,6 +78,7 @@ SIGNATURES = {
     "rp_batch_event_record": (ctypes.c_int, [_vp, ctypes.c_int]),
     "rp_batch_event_elapsed_ms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
     "rp_batch_field_ptr": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "rp_batch_slot_map": (ctypes.c_int, [_vp, _vp]),
 }
 
 _lib = None

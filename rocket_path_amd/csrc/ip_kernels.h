@@ -9,8 +9,8 @@
 
 namespace rp {
 
-// Device-side view of one batch: `fields` SoA arrays of `n` elements, field f at
-// base + f * stride (stride >= n, an odd multiple of 512 elements: 2-4 KiB aligned fields that do not alias in HBM, rp_batch.cpp).
+// Device-side view of one batch: `fields` SoA arrays of `n` elements, field f of the problem at POSITION s at
+// base + f * stride + s (stride >= n, an odd multiple of 512 elements: 2-4 KiB aligned fields that do not alias in HBM, rp_batch.cpp).
 struct BatchView {
     void *base;            // double* or float*
     size_t stride;         // elements between consecutive fields
@@ -20,7 +20,9 @@ struct BatchView {
     bool zero_end_vel;     // vel0X == vel2X == 0 for every problem (true after every init the reference has; see Prob in ip_core.h)
     int32_t *iters;        // gated Newton steps taken per problem
     uint32_t *status;      // RP_ST_* bits per problem
-    uint16_t *order;       // scheduling permutation for the fused solve (k_order_tiles): tile-local indices
+    uint32_t *slot_of;     // scheduled order (k_schedule_windows): problem index -> position in the batch ...
+    uint32_t *prob_of;     // ... and position -> problem index; both n words, meaningful while `scheduled`
+    bool scheduled;        // false: the problems lie in problem order (identical problems of initDefault / initStuck)
     unsigned long long *counters;   // 128 words: [0,64) shards of "problems still open after the last gated launch", [64,128) shards of gated steps executed
 };
 
@@ -42,7 +44,7 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
 hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k, uint32_t *d_nfeas, uint32_t *d_nresid, hipStream_t stream);
 // up to k gated steps per problem (k = max_iter gives the fused solve); zeroes counters[0] first.
 hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream);
-// the fused solve (every problem to its gate in one launch), tiled and ordered by expected step count
+// the fused solve (every problem to its gate in one launch)
 hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, hipStream_t stream);
 // max ||r||^2, max gap, #converged, gated steps (+ host_steps) -> d_out4 (device); d_partials has 4 * 1024 doubles.
 hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_steps, double *d_partials,
@@ -57,14 +59,16 @@ hipError_t launch_restart_feasible(const BatchView &b, const HostParams &hp, hip
 hipError_t launch_init_const(const BatchView &b, const double *host_state /* state_len values */, hipStream_t stream);
 hipError_t launch_nudge(const BatchView &b, int field, double delta, hipStream_t stream);
 hipError_t launch_clear_progress(const BatchView &b, hipStream_t stream);
-// recompute the scheduling order from the positions currently in the batch
-hipError_t launch_order(const BatchView &b, hipStream_t stream);
+// compute the scheduled order (slot_of / prob_of) from positions given as three strided double arrays in problem order
+hipError_t launch_schedule(const BatchView &b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride, hipStream_t stream);
+// d_dst[problem] = d_src[position of that problem] for per-problem words kept in batch order (requires b.scheduled)
+hipError_t launch_gather_u32(const BatchView &b, const uint32_t *d_src, uint32_t *d_dst, hipStream_t stream);
 
 // the rows either side of the hot path
 hipError_t launch_move_toward_feasibility(const BatchView &b, const HostParams &hp, hipStream_t stream);
 hipError_t launch_sample(const BatchView &b, double *d_pos66, double *d_acc4, hipStream_t stream);
 
-// the same on a window [first, first + count) of the batch, plus printState's constraint table (1 + 14 m doubles per problem)
+// the same for problems [first, first + count), plus printState's constraint table (1 + 14 m doubles per problem)
 hipError_t launch_soa_to_aos_range(const BatchView &b, size_t first, size_t count, double *d_aos, hipStream_t stream);
 hipError_t launch_sample_range(const BatchView &b, size_t first, size_t count, double *d_pos66, double *d_acc4, hipStream_t stream);
 hipError_t launch_constraint_table(const BatchView &b, const HostParams &hp, size_t first, size_t count, double *d_rows, hipStream_t stream);

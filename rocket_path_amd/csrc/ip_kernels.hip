@@ -8,18 +8,24 @@
 // channel).  One Newton step reads 16 and writes 11 fields (F3): 216 B per problem per step, the
 // algorithmic traffic of SURVEY.md 8d; the kernels instantiated for zero end velocities read 14.
 //
-// Launch shapes, all sharing the per-lane step of ip_core.h, all with 256-thread blocks:
-//   k_solve_tiled      the fused gated solve (the benchmark's kernel; 140 VGPRs, 3 waves per SIMD) and, ungated,
-//                      k >= 3 steps on large batches: one 512-problem tile per block, staged in LDS and
-//                      scheduled by expected step count
+// Within the batch the problems lie in SCHEDULED order (k_schedule_windows, run when positions are set): every window of
+// 4,096 consecutive problems is sorted by its segment-length ratio min|dX| / max|dX|, which predicts the gated step count
+// (problems with similar segments take longest).  slot_of[] / prob_of[] map problem index <-> position; only the kernels at
+// the ABI boundary (state in / out, read-backs by problem index) look at them, the Newton kernels walk positions.
+//
+// Launch shapes, all sharing the per-lane step of ip_core.h:
+//   k_solve_chunks     the gated solve (the benchmark's kernel): one 64-problem chunk of the scheduled order per
+//                      single-wave block, state in registers from its first load to its last store, no LDS, longest
+//                      chunks dispatched first
+//   k_steps_tiled      k >= 3 ungated steps on large batches: one 512-problem tile per 256-thread block, staged in LDS
+//                      (this is the form whose registers fit three waves per SIMD)
 //   k_newton_stream16  k <= 2 ungated steps, the HBM-streaming form: 16 B per lane (two doubles / four floats =
 //                      that many consecutive problems per lane), one global_load/store_dwordx4 per field
 //   k_newton_stream    the same with one problem per lane and a register prefetch: ragged remainders, small
 //                      batches with k >= 3 (more waves than the 16-byte form), mu_mode 1
 //   k_steps_regrouped  F4's long fixed-step runs (k >= 20) on large batches: tiles re-sorted by line-search cost every 4 steps
-//   k_newton           one problem per lane in batch order, gated: small batches, host-polled gated loops, mu_mode 1
-// Problems are independent and nothing is re-read, so there is no L2 locality to arrange: the
-// plain blockIdx -> problem-range map is XCD-neutral (blocks are dealt round-robin over the 8 XCDs).
+// Problems are independent and nothing is re-read, so there is no L2 locality to arrange: consecutive blocks are dealt
+// round-robin over the 8 XCDs and touch disjoint cache lines.
 #include "ip_kernels.h"
 
 #include <cstdlib>
@@ -33,6 +39,18 @@ namespace rp {
 namespace {
 
 constexpr int kBlock = 256;
+// The scheduled order: windows of kWindow problems, each sorted; a chunk = 64 consecutive positions = one wave of the gated solve.
+constexpr int kWindow = 4096;
+constexpr int kChunksPerWindow = kWindow / 64;
+
+// once-per-launch global accesses (state in, results out): nontemporal, they are never re-read through the caches
+#if !defined(RP_STREAM_PLAIN) && !defined(RP_TILE_PLAIN)
+template <typename S> __device__ __forceinline__ S ld_once(const S *p) { return __builtin_nontemporal_load(p); }
+template <typename S> __device__ __forceinline__ void st_once(S *p, S v) { __builtin_nontemporal_store(v, p); }
+#else
+template <typename S> __device__ __forceinline__ S ld_once(const S *p) { return *p; }
+template <typename S> __device__ __forceinline__ void st_once(S *p, S v) { *p = v; }
+#endif
 // Progress counters are sharded over 64 words each (open lanes: [0,64), gated steps: [64,128)):
 // one word takes ~88 atomics/us, and a k = 1 gated launch ends with 16384 waves arriving at once
 // (measured: 0.34 ms of a 0.40 ms launch was the two single-word atomics).
@@ -64,7 +82,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 }
 
 // ---------------------------------------------------------------------------------------
-// k_newton: up to k Newton steps per problem, state in registers between steps.
+// run_lane: up to k Newton steps of one problem, state in registers between steps.
 //   GATED = false : exactly k steps (k presses of 'n', onedpath_ip.cpp:269-272)
 //   GATED = true  : before each step stop if gap < tol or the problem's step count reached
 //                   max_iter; problems already finished are skipped
@@ -161,33 +179,48 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     run_lane<T, VARIANT, GATED, STALL, P, S, AFFINE, MU, NoDiag>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open, none);
 }
 
-template <typename S, typename T, int VARIANT, bool GATED, bool ZV, int MU = 0>
-__global__ void __launch_bounds__(kBlock, RP_NEWTON_WAVES)
-k_newton(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
-         int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters)
+// ---------------------------------------------------------------------------------------
+// The gated solve: up to k gated steps per problem (k = max_iter: every problem to its gate in one launch, the
+// benchmark's form; smaller k: one round of a host-polled or globally checked loop).  A wave runs until its slowest lane
+// has converged and gated step counts differ from problem to problem (12-20 on the benchmark distribution), so in arbitrary
+// order ~20 % of the lane-steps of a fused solve are idle.  The batch is therefore kept in scheduled order (see the top
+// of this file) and each single-wave block takes one 64-problem chunk of it: lanes of similar expected length, loaded and
+// stored as full coalesced segments with no LDS and no block barrier in between.  With one wave per block the hardware
+// dispatcher IS the work queue: a wave that finishes early frees its slot for the next chunk, so the tail of the grid is
+// one chunk long instead of one 512-problem tile (which cost 11 % at 1 Mi problems: 2,048 tiles over 768 slots), and
+// the blocks are numbered so that the longest chunks (highest ratio rank, one from every window in turn) start first.
+// Which lane solves which problem changes nothing in any problem's result (lanes never interact); a stale order
+// (positions nudged after it was computed) is merely a less effective schedule.
+// (mu_mode 1 carries the split direction: ~210 VGPRs, two waves per SIMD)
+template <typename S, typename T, int VARIANT, bool STALL, bool ZV, int MU = 0>
+__global__ void __launch_bounds__(64, MU == 1 ? RP_NEWTON_WAVES : RP_TILED_WAVES)
+k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
+               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;   // first constant field: pos0, vel0, pos1, pos2, vel2
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = i < n;
+    const unsigned windows = (unsigned)((n + kWindow - 1) / kWindow);      // gridDim.x == windows * kChunksPerWindow
+    const unsigned rank = kChunksPerWindow - 1 - blockIdx.x / windows, window = blockIdx.x % windows;
+    const size_t i = (size_t)window * kWindow + (size_t)rank * 64 + threadIdx.x;
 
     int it = 0;
     uint32_t st = 0;
-    bool active = valid;
-    if (GATED && valid) {
+    bool active = i < n;
+    if (active) {
         it = iters[i];
         st = status[i];
         active = (st & (RP_ST_CONVERGED | RP_ST_MAXITER | RP_ST_STALLED)) == 0;
     }
+    if (__ballot(active) == 0) return;      // past the end of a ragged window, or a chunk that finished in an earlier launch
     int steps_here = 0;
     bool still_open = false;
 
     if (active) {
         S *f = base + i;
-        T v = (T)f[0 * stride], t0 = (T)f[1 * stride], t1 = (T)f[2 * stride];
+        T v = (T)ld_once(f + 0 * stride), t0 = (T)ld_once(f + 1 * stride), t1 = (T)ld_once(f + 2 * stride);
         T lam[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) lam[c] = (T)f[(3 + c) * stride];
+        for (int c = 0; c < NC; ++c) lam[c] = (T)ld_once(f + (3 + c) * stride);
         Prob<T, ZV> pr;
         {
             const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
@@ -198,28 +231,24 @@ k_newton(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T 
             pr.dx0 = p1 - p0;
             pr.dx1 = p2 - p1;
         }
-        run_lane<T, VARIANT, GATED, GATED, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
-        if (GATED) {
-            iters[i] = it;
-            status[i] = st;
-        }
+        run_lane<T, VARIANT, true, STALL, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+        iters[i] = it;
+        status[i] = st;
         if (steps_here > 0) {
-            f[0 * stride] = (S)v;
-            f[1 * stride] = (S)t0;
-            f[2 * stride] = (S)t1;
+            st_once(f + 0 * stride, (S)v);
+            st_once(f + 1 * stride, (S)t0);
+            st_once(f + 2 * stride, (S)t1);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = (S)lam[c];
+            for (int c = 0; c < NC; ++c) st_once(f + (3 + c) * stride, (S)lam[c]);
         }
     }
 
-    if (GATED) {
-        const unsigned long long open_mask = __ballot(still_open);
-        const int steps_wave = wave_sum<int>(steps_here);
-        if ((threadIdx.x & 63) == 0) {
-            const unsigned shard = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kShards - 1);
-            if (open_mask) atomicAdd(&counters[shard], (unsigned long long)__popcll(open_mask));
-            if (steps_wave) atomicAdd(&counters[kShards + shard], (unsigned long long)steps_wave);
-        }
+    const unsigned long long open_mask = __ballot(still_open);
+    const int steps_wave = wave_sum<int>(steps_here);
+    if (threadIdx.x == 0) {
+        const unsigned shard = blockIdx.x & (kShards - 1);
+        if (open_mask) atomicAdd(&counters[shard], (unsigned long long)__popcll(open_mask));
+        if (steps_wave) atomicAdd(&counters[kShards + shard], (unsigned long long)steps_wave);
     }
 }
 
@@ -405,21 +434,11 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
 }
 
 // ---------------------------------------------------------------------------------------
-// The fused gated solve, tiled and scheduled.  A wave runs until its slowest lane has
-// converged, and gated step counts differ from problem to problem (12-20 on the benchmark
-// distribution; problems whose two segments have similar length take longest), so in batch
-// order ~20 % of the lane-steps of a fused solve are idle.
-//
-// k_order_tiles (run when positions are set, not per solve) computes for every tile of 512
-// consecutive problems a permutation of the tile ordered by the segment-length ratio
-// min|dX|/max|dX| (64-bucket counting sort in LDS).  k_solve_tiled gives each 256-thread block
-// one tile: it stages the tile's 11 MUTABLE fields in LDS (44 KiB in f64, coalesced both ways -- the
-// permutation never touches global addresses; the five constants are gathered once per problem inside
-// the tile's 4 KiB windows), and wave w solves sorted chunks w and 7-w, so
-// the 64 lanes of a wave hold problems of similar expected length and the four waves finish
-// together.  Idle lane-steps drop from 19 % to 5 % (2.7 % with a perfect predictor).  Which lane solves
-// which problem changes nothing in any problem's result (lanes never interact); a stale order
-// (positions nudged after it was computed) is merely a less effective schedule.
+// k ungated steps per problem on large batches, tiled.  For k >= 3 the arithmetic dominates; the fixed-step body needs
+// ~165 VGPRs, and a kernel that loads its 16 fields straight into registers while the previous values are still live does
+// not fit three waves per SIMD.  Here each 256-thread block stages one tile of 512 consecutive problems in LDS (the 11
+// MUTABLE fields, 44 KiB in f64, coalesced both ways; the five constants are read once per problem) and every lane
+// steps two of them one after the other out of LDS: 168 VGPRs, no scratch, three blocks per CU.
 #ifndef RP_TILE
 #define RP_TILE 512      // problems per tile of the tiled kernels; their blocks have RP_TILE / 2 threads (each wave two 64-problem chunks)
 #endif
@@ -428,71 +447,14 @@ constexpr int kTileThreads = kTile / 2;
 constexpr size_t kTiledMin = 262144;      // below this many problems the tiled kernels cannot fill the chip
 constexpr int kBuckets = 64;
 
-// once-per-launch global accesses of the tiled kernels (tile staging in, results out)
-#if !defined(RP_STREAM_PLAIN) && !defined(RP_TILE_PLAIN)
-template <typename S> __device__ __forceinline__ S ld_once(const S *p) { return __builtin_nontemporal_load(p); }
-template <typename S> __device__ __forceinline__ void st_once(S *p, S v) { __builtin_nontemporal_store(v, p); }
-#else
-template <typename S> __device__ __forceinline__ S ld_once(const S *p) { return *p; }
-template <typename S> __device__ __forceinline__ void st_once(S *p, S v) { *p = v; }
-#endif
-
-template <typename T, int VARIANT>
-__global__ void __launch_bounds__(kTileThreads)
-k_order_tiles(const T *__restrict__ base, size_t stride, size_t n, uint16_t *__restrict__ order)
-{
-    constexpr int CB = 3 + CMap<VARIANT>::NC;
-    constexpr int PER = kTile / kTileThreads;
-    __shared__ unsigned s_hist[kBuckets], s_start[kBuckets], s_fill[kBuckets];
-    const int tid = threadIdx.x;
-    const size_t first = (size_t)blockIdx.x * kTile;
-    const int count = (n - first < (size_t)kTile) ? (int)(n - first) : kTile;
-    if (tid < kBuckets) { s_hist[tid] = 0; s_fill[tid] = 0; }
-    __syncthreads();
-    int key[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int j = tid + q * kTileThreads;
-        key[q] = -1;
-        if (j < count) {
-            const T p0 = base[(size_t)(CB + 0) * stride + first + j], p1 = base[(size_t)(CB + 2) * stride + first + j];
-            const T p2 = base[(size_t)(CB + 3) * stride + first + j];
-            const T d0 = abs_(p1 - p0), d1 = abs_(p2 - p1);
-            const T lo = d0 < d1 ? d0 : d1, hi = d0 < d1 ? d1 : d0;
-            const T r = lo / hi * T(kBuckets);
-            key[q] = (r >= T(0) && r < T(kBuckets)) ? (int)r : kBuckets - 1;   // equal lengths / NaN -> last bucket
-            atomicAdd(&s_hist[key[q]], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned acc = 0;
-        for (int b = 0; b < kBuckets; ++b) { s_start[b] = acc; acc += s_hist[b]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        if (key[q] >= 0) {
-            const unsigned pos = s_start[key[q]] + atomicAdd(&s_fill[key[q]], 1u);
-            order[first + pos] = (uint16_t)(tid + q * kTileThreads);      // tile-local index
-        }
-    }
-}
-
-// GATED = true: the fused gated solve.  GATED = false: k ungated steps per problem through the same tile
-// staging (for k >= 3 the arithmetic dominates, and this is the form that fits three waves per SIMD).
 // Every instantiation fits 168 VGPRs without scratch (profiles/kernel_resources.py; any scratch makes the launch time erratic).
-template <typename S, typename T, int VARIANT, bool GATED, bool STALL, bool ZV>
+template <typename S, typename T, int VARIANT, bool ZV>
 __global__ void __launch_bounds__(kTileThreads, RP_TILED_WAVES)
-k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
-              int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
-              const uint16_t *__restrict__ order)
+k_steps_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
     __shared__ S sm[CB][kTile];            // the mutable fields only; the five constants are read once per problem
-    __shared__ int32_t s_it[GATED ? kTile : 1];
-    __shared__ uint32_t s_st[GATED ? kTile : 1];
 
     const int tid = threadIdx.x;
     const size_t first = (size_t)blockIdx.x * kTile;
@@ -502,31 +464,17 @@ k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
 #pragma unroll
     for (int f = 0; f < CB; ++f)
         for (int j = tid; j < count; j += kTileThreads) sm[f][j] = ld_once(base + (size_t)f * stride + first + j);
-    if (GATED)
-        for (int j = tid; j < count; j += kTileThreads) { s_it[j] = iters[first + j]; s_st[j] = status[first + j]; }
-    // this thread's two scheduled problems: sorted chunks `wave` and `7 - wave`
-    const int wave = tid >> 6, lane = tid & 63;
-    int mine[2];
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
-        const int slot = (round == 0 ? wave : (kTile / 64 - 1 - wave)) * 64 + lane;
-        mine[round] = slot < count ? (int)order[first + slot] : -1;
-    }
     __syncthreads();
 
-    int steps_here = 0;
-    bool open_any = false;
 #pragma unroll 1
     for (int round = 0; round < 2; ++round) {
-        const int j = mine[round];
-        bool live = j >= 0;
-        if (GATED && live) live = (s_st[j] & (RP_ST_CONVERGED | RP_ST_MAXITER | RP_ST_STALLED)) == 0;
-        if (live) {
+        const int j = round * kTileThreads + tid;
+        if (j < count) {
             T v = (T)sm[0][j], t0 = (T)sm[1][j], t1 = (T)sm[2][j];
             T lam[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) lam[c] = (T)sm[3 + c][j];
-            Prob<T, ZV> pr;     // constants: a gather inside the tile's 4 KiB window of each field, once per problem
+            Prob<T, ZV> pr;
             {
                 const S *g = base + first + j;
                 const T q0 = (T)g[(size_t)(CB + 0) * stride], q1 = (T)g[(size_t)(CB + 2) * stride], q2 = (T)g[(size_t)(CB + 3) * stride];
@@ -537,37 +485,25 @@ k_solve_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> k
                 pr.dx0 = q1 - q0;
                 pr.dx1 = q2 - q1;
             }
-            int it = GATED ? s_it[j] : 0;
-            uint32_t st = GATED ? s_st[j] : 0u;
+            int it = 0, steps_here = 0;
+            uint32_t st = 0u;
             bool still_open = false;
             // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
             // its stalled problems), so all its fixed-step kernels use it and agree bit for bit; F3's tiled kernel would spill
-            run_lane<T, VARIANT, GATED, STALL, Prob<T, ZV>, S, (VARIANT == 4)>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
-            open_any = open_any || still_open;
+            run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
             sm[0][j] = (S)v;
             sm[1][j] = (S)t0;
             sm[2][j] = (S)t1;
 #pragma unroll
             for (int c = 0; c < NC; ++c) sm[3 + c][j] = (S)lam[c];
-            if (GATED) { s_it[j] = it; s_st[j] = st; }
         }
     }
     __syncthreads();
 
-    // -- write the tile back: mutable fields and progress words
+    // -- write the tile back
 #pragma unroll
     for (int f = 0; f < CB; ++f)
         for (int j = tid; j < count; j += kTileThreads) st_once(base + (size_t)f * stride + first + j, sm[f][j]);
-    if (GATED) {
-        for (int j = tid; j < count; j += kTileThreads) { iters[first + j] = s_it[j]; status[first + j] = s_st[j]; }
-        const unsigned long long open_mask = __ballot(open_any);
-        const int steps_wave = wave_sum<int>(steps_here);
-        if (lane == 0) {
-            const unsigned shard = (blockIdx.x * (kTileThreads / 64) + wave) & (kShards - 1);
-            if (open_mask) atomicAdd(&counters[shard], (unsigned long long)__popcll(open_mask));
-            if (steps_wave) atomicAdd(&counters[kShards + shard], (unsigned long long)steps_wave);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -655,7 +591,7 @@ k_steps_regrouped(S *__restrict__ base, size_t stride, size_t n, int k, int ever
             }
         }
         __syncthreads();
-        if (done + every < k) {      // counting sort of the tile's problems by bucket (as k_order_tiles)
+        if (done + every < k) {      // counting sort of the tile's problems by bucket (LDS atomics)
             if (tid < kBuckets) { s_hist[tid] = 0; s_fill[tid] = 0; }
             __syncthreads();
             for (int j = tid; j < count; j += kTileThreads) atomicAdd(&s_hist[s_key[j]], 1u);
@@ -764,9 +700,10 @@ k_reduce_final(const double *__restrict__ partials, int nblocks, const unsigned 
 // LDS so that both the global reads and the global writes are fully coalesced.  Rows are
 // padded by one double: a lane reading its problem's field f then hits bank (34 l + 2 f) % 64,
 // a 2-way conflict instead of the 32-way one of an unpadded 16-double row.
+// `slot_of` (null = identity) maps problem index -> position in the batch: the AoS side is always in problem order.
 template <typename T, int M>
 __global__ void __launch_bounds__(kBlock)
-k_aos_to_soa(const double *__restrict__ aos, T *__restrict__ base, size_t stride, size_t n)
+k_aos_to_soa(const double *__restrict__ aos, T *__restrict__ base, size_t stride, size_t n, const uint32_t *__restrict__ slot_of)
 {
     __shared__ double tile[kBlock * (M + 1)];
     const size_t first = (size_t)blockIdx.x * kBlock;
@@ -775,25 +712,81 @@ k_aos_to_soa(const double *__restrict__ aos, T *__restrict__ base, size_t stride
     for (size_t j = threadIdx.x; j < count * M; j += kBlock) tile[(j / M) * (M + 1) + (j % M)] = src[j];
     __syncthreads();
     if (threadIdx.x < count) {
+        const size_t at = slot_of ? (size_t)slot_of[first + threadIdx.x] : first + threadIdx.x;
 #pragma unroll
-        for (int f = 0; f < M; ++f) base[(size_t)f * stride + first + threadIdx.x] = (T)tile[threadIdx.x * (M + 1) + f];
+        for (int f = 0; f < M; ++f) base[(size_t)f * stride + at] = (T)tile[threadIdx.x * (M + 1) + f];
     }
 }
 
+// problems [first, first + count) -> aos rows 0 .. count-1
 template <typename T, int M>
 __global__ void __launch_bounds__(kBlock)
-k_soa_to_aos(const T *__restrict__ base, size_t stride, size_t n, double *__restrict__ aos)
+k_soa_to_aos(const T *__restrict__ base, size_t stride, size_t first, size_t count, const uint32_t *__restrict__ slot_of, double *__restrict__ aos)
 {
     __shared__ double tile[kBlock * (M + 1)];
-    const size_t first = (size_t)blockIdx.x * kBlock;
-    const size_t count = (n - first < (size_t)kBlock) ? (n - first) : (size_t)kBlock;
-    if (threadIdx.x < count) {
+    const size_t row0 = (size_t)blockIdx.x * kBlock;
+    const size_t rows = (count - row0 < (size_t)kBlock) ? (count - row0) : (size_t)kBlock;
+    if (threadIdx.x < rows) {
+        const size_t i = first + row0 + threadIdx.x;
+        const size_t at = slot_of ? (size_t)slot_of[i] : i;
 #pragma unroll
-        for (int f = 0; f < M; ++f) tile[threadIdx.x * (M + 1) + f] = (double)base[(size_t)f * stride + first + threadIdx.x];
+        for (int f = 0; f < M; ++f) tile[threadIdx.x * (M + 1) + f] = (double)base[(size_t)f * stride + at];
     }
     __syncthreads();
-    double *dst = aos + first * M;
-    for (size_t j = threadIdx.x; j < count * M; j += kBlock) dst[j] = tile[(j / M) * (M + 1) + (j % M)];
+    double *dst = aos + row0 * M;
+    for (size_t j = threadIdx.x; j < rows * M; j += kBlock) dst[j] = tile[(j / M) * (M + 1) + (j % M)];
+}
+
+// per-problem words kept in batch order (iters, status, halving counts) -> problem order
+__global__ void __launch_bounds__(kBlock)
+k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ slot_of, size_t n, uint32_t *__restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = src[slot_of[i]];
+}
+
+// ---------------------------------------------------------------------------------------
+// The scheduled order.  One 1,024-thread block per window of kWindow problems: key = the segment-length ratio
+// min|dX| / max|dX| quantised to 20 bits, tie-broken by the problem's index in the window (so the order is a pure function
+// of the positions), bitonic sort in LDS, ascending: the problems expected to take longest end up in the window's last
+// chunks.  Positions come as three strided double arrays (separate arrays: pstride 1; rows of an AoS state: pstride M).
+__global__ void __launch_bounds__(1024)
+k_schedule_windows(const double *__restrict__ pos0, const double *__restrict__ pos1, const double *__restrict__ pos2, size_t pstride,
+                   size_t n, uint32_t *__restrict__ slot_of, uint32_t *__restrict__ prob_of)
+{
+    __shared__ uint32_t key[kWindow];
+    const int tid = threadIdx.x;
+    const size_t first = (size_t)blockIdx.x * kWindow;
+    const int count = (n - first < (size_t)kWindow) ? (int)(n - first) : kWindow;
+    for (int j = tid; j < kWindow; j += 1024) {
+        uint32_t q = 0xFFFFFFFFu;      // padding sorts behind every problem
+        if (j < count) {
+            const size_t at = (first + j) * pstride;
+            const double d0 = __builtin_fabs(pos1[at] - pos0[at]), d1 = __builtin_fabs(pos2[at] - pos1[at]);
+            const double lo = d0 < d1 ? d0 : d1, hi = d0 < d1 ? d1 : d0;
+            const double r = lo / hi * 1048575.0;
+            const uint32_t bucket = (r >= 0.0 && r < 1048575.0) ? (uint32_t)r : 1048574u;      // equal lengths / NaN -> last
+            q = (bucket << 12) | (uint32_t)j;
+        }
+        key[j] = q;
+    }
+    __syncthreads();
+    for (int size = 2; size <= kWindow; size <<= 1) {
+        for (int dist = size >> 1; dist > 0; dist >>= 1) {
+            for (int t = tid; t < kWindow / 2; t += 1024) {
+                const int lo = ((t / dist) * 2 * dist) + (t % dist), hi = lo + dist;
+                const bool ascending = (lo & size) == 0;
+                const uint32_t a = key[lo], b = key[hi];
+                if ((a > b) == ascending) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < count; j += 1024) {
+        const uint32_t local = key[j] & 0xFFFu;
+        prob_of[first + j] = (uint32_t)(first + local);
+        slot_of[first + local] = (uint32_t)(first + j);
+    }
 }
 
 // Feasible start (build-defined): vel1 = 0, t_i = (3.5/sqrt 12) sqrt(6 |dX_i| / L),
@@ -801,13 +794,14 @@ k_soa_to_aos(const T *__restrict__ base, size_t stride, size_t n, double *__rest
 template <typename T, int VARIANT>
 __global__ void __launch_bounds__(kBlock)
 k_init_feasible(T *__restrict__ base, size_t stride, size_t n, double limit, const double *__restrict__ pos0,
-                const double *__restrict__ pos1, const double *__restrict__ pos2)
+                const double *__restrict__ pos1, const double *__restrict__ pos2, const uint32_t *__restrict__ prob_of)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;      // position in the batch
     if (i >= n) return;
-    const double p0 = pos0[i], p1 = pos1[i], p2 = pos2[i];
+    const size_t who = prob_of ? (size_t)prob_of[i] : i;             // the problem that lives there
+    const double p0 = pos0[who], p1 = pos1[who], p2 = pos2[who];
     const double scale = 3.5 / __builtin_sqrt(12.0);
     T *f = base + i;
     f[0 * stride] = T(0);
@@ -904,14 +898,15 @@ k_move_toward_feasibility(S *__restrict__ base, size_t stride, size_t n, KParams
 // onedpath_ip.cpp:1065-1088, 33 per segment) and 4 end accelerations (plotAcceleration, 1024-1027).
 template <typename T, int VARIANT>
 __global__ void __launch_bounds__(kBlock)
-k_sample(const T *__restrict__ base, size_t stride, size_t n, double *__restrict__ pos66, double *__restrict__ acc4)
+k_sample(const T *__restrict__ base, size_t stride, size_t first, size_t count, const uint32_t *__restrict__ slot_of,
+         double *__restrict__ pos66, double *__restrict__ acc4)
 {
     constexpr int CB = 3 + CMap<VARIANT>::NC;
     const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const size_t i = idx / 70;
+    const size_t i = idx / 70;      // output row: problem first + i
     const int slot = (int)(idx % 70);
-    if (i >= n) return;
-    const T *f = base + i;
+    if (i >= count) return;
+    const T *f = base + (slot_of ? (size_t)slot_of[first + i] : first + i);
     const double v1 = (double)f[0], t0 = (double)f[1 * stride], t1 = (double)f[2 * stride];
     const double p0 = (double)f[(CB + 0) * stride], v0 = (double)f[(CB + 1) * stride], p1 = (double)f[(CB + 2) * stride];
     const double p2 = (double)f[(CB + 3) * stride], v2 = (double)f[(CB + 4) * stride];
@@ -947,14 +942,15 @@ k_sample(const T *__restrict__ base, size_t stride, size_t n, double *__restrict
 // printed is what the kernels step on.
 template <typename S, typename T, int VARIANT>
 __global__ void __launch_bounds__(kBlock)
-k_constraint_table(const S *__restrict__ base, size_t stride, size_t first, size_t count, KParams<T> kp, double *__restrict__ out)
+k_constraint_table(const S *__restrict__ base, size_t stride, size_t first, size_t count, const uint32_t *__restrict__ slot_of,
+                   KParams<T> kp, double *__restrict__ out)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
     constexpr int ROW = 1 + 14 * NC;
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= count) return;
-    const S *f = base + first + j;
+    const S *f = base + (slot_of ? (size_t)slot_of[first + j] : first + j);
     Prob<T> pr;
     const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
     pr.v0 = (T)f[(CB + 1) * stride];
@@ -1066,10 +1062,8 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
                                                                       (S *)b.base, b.stride, b.n, k, every, make_kparams<T>(hp, 4)));
             return hipGetLastError();
         }
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, false, false, Z>), dim3(tiles), dim3(kTileThreads), 0, stream,
-                                             (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), T(0), 0,
-                                             (int32_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr,
-                                             (const uint16_t *)b.order));
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_tiled<S, T, V, Z>), dim3(tiles), dim3(kTileThreads), 0, stream,
+                                             (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
         return hipGetLastError();
     }
     // k <= 2: memory-bound.  Full blocks of 256 lanes x 16 B go through k_newton_stream16; the ragged remainder (and,
@@ -1100,59 +1094,49 @@ hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k,
     return hipGetLastError();
 }
 
+// the gated solve: up to k gated steps per problem, one 64-problem chunk of the scheduled order per single-wave block
+static hipError_t launch_chunks(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream)
+{
+    const unsigned windows = (unsigned)((b.n + kWindow - 1) / kWindow);
+    const dim3 grid(windows * kChunksPerWindow), block(64);
+    if (hp.mu_mode == 1)
+        RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, true, Z, 1>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
+                                                 make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters));
+    else if (hp.stall_window > 0)
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, true, Z>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
+                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters));
+    else
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, false, Z>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
+                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters));
+    return hipGetLastError();
+}
+
 hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
     // (the open-lane shards are not zeroed here: only the host-polled loop reads them, and launch_solve zeroes them itself)
-    // Below ~2 tiles per CU slot the tiled kernel cannot fill the chip (one 256-thread block per
-    // 512 problems): small batches take the plain one-problem-per-lane kernel.
-    static const bool no_tiled = getenv("RP_NO_TILED") != nullptr;     // A/B switch for tuning
-    if (hp.mu_mode == 1) {
-        RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z, 1>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                                 (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
-                                                 (T)gap_tol, max_iter, b.iters, b.status, b.counters));
-        return hipGetLastError();
-    }
-    if (no_tiled || b.n < kTiledMin) {
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                             (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
-                                             (T)gap_tol, max_iter, b.iters, b.status, b.counters));
-        return hipGetLastError();
-    }
-    const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
-    if (hp.stall_window > 0)
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, true, true, Z>), dim3(grid), dim3(kTileThreads), 0, stream,
-                                             (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
-                                             (T)gap_tol, max_iter, b.iters, b.status, b.counters, (const uint16_t *)b.order));
-    else
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_tiled<S, T, V, true, false, Z>), dim3(grid), dim3(kTileThreads), 0, stream,
-                                             (S *)b.base, b.stride, b.n, max_iter > 0 ? max_iter : 1, make_kparams<T>(hp, V),
-                                             (T)gap_tol, max_iter, b.iters, b.status, b.counters, (const uint16_t *)b.order));
-    return hipGetLastError();
-}
-
-hipError_t launch_order(const BatchView &b, hipStream_t stream)
-{
-    if (b.n == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((b.n + kTile - 1) / kTile);
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_order_tiles<S, V>), dim3(grid), dim3(kTileThreads), 0, stream,
-                                       (const S *)b.base, b.stride, b.n, b.order));
-    return hipGetLastError();
+    return launch_chunks(b, hp, max_iter > 0 ? max_iter : 1, gap_tol, max_iter, stream);
 }
 
 hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(kShards), 0, stream, b.counters);
-    if (hp.mu_mode == 1) {
-        RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z, 1>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                                 (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
-                                                 b.iters, b.status, b.counters));
-        return hipGetLastError();
-    }
-    RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton<S, T, V, true, Z>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                         (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), (T)gap_tol, max_iter,
-                                         b.iters, b.status, b.counters));
+    return launch_chunks(b, hp, k, gap_tol, max_iter, stream);
+}
+
+hipError_t launch_schedule(const BatchView &b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    const unsigned windows = (unsigned)((b.n + kWindow - 1) / kWindow);
+    hipLaunchKernelGGL(k_schedule_windows, dim3(windows), dim3(1024), 0, stream, d_pos0, d_pos1, d_pos2, pstride, b.n, b.slot_of, b.prob_of);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_u32(const BatchView &b, const uint32_t *d_src, uint32_t *d_dst, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(b.n)), dim3(kBlock), 0, stream, d_src, (const uint32_t *)b.slot_of, b.n, d_dst);
     return hipGetLastError();
 }
 
@@ -1167,37 +1151,43 @@ hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_s
     return hipGetLastError();
 }
 
+static const uint32_t *slots(const BatchView &b) { return b.scheduled ? b.slot_of : nullptr; }
+
 hipError_t launch_aos_to_soa(const BatchView &b, const double *d_aos, hipStream_t stream)
 {
     const dim3 g(grid_for(b.n)), t(kBlock);
     if (b.dtype == 0) {      // storage type only: dtype 1 and 2 both keep floats
-        if (b.variant == 3) hipLaunchKernelGGL((k_aos_to_soa<double, 16>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n);
-        else                hipLaunchKernelGGL((k_aos_to_soa<double, 12>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n);
+        if (b.variant == 3) hipLaunchKernelGGL((k_aos_to_soa<double, 16>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n, slots(b));
+        else                hipLaunchKernelGGL((k_aos_to_soa<double, 12>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n, slots(b));
     } else {
-        if (b.variant == 3) hipLaunchKernelGGL((k_aos_to_soa<float, 16>), g, t, 0, stream, d_aos, (float *)b.base, b.stride, b.n);
-        else                hipLaunchKernelGGL((k_aos_to_soa<float, 12>), g, t, 0, stream, d_aos, (float *)b.base, b.stride, b.n);
+        if (b.variant == 3) hipLaunchKernelGGL((k_aos_to_soa<float, 16>), g, t, 0, stream, d_aos, (float *)b.base, b.stride, b.n, slots(b));
+        else                hipLaunchKernelGGL((k_aos_to_soa<float, 12>), g, t, 0, stream, d_aos, (float *)b.base, b.stride, b.n, slots(b));
     }
     return hipGetLastError();
 }
 
-hipError_t launch_soa_to_aos(const BatchView &b, double *d_aos, hipStream_t stream)
+hipError_t launch_soa_to_aos_range(const BatchView &b, size_t first, size_t count, double *d_aos, hipStream_t stream)
 {
-    const dim3 g(grid_for(b.n)), t(kBlock);
+    if (count == 0) return hipSuccess;
+    const dim3 g(grid_for(count)), t(kBlock);
     if (b.dtype == 0) {
-        if (b.variant == 3) hipLaunchKernelGGL((k_soa_to_aos<double, 16>), g, t, 0, stream, (const double *)b.base, b.stride, b.n, d_aos);
-        else                hipLaunchKernelGGL((k_soa_to_aos<double, 12>), g, t, 0, stream, (const double *)b.base, b.stride, b.n, d_aos);
+        if (b.variant == 3) hipLaunchKernelGGL((k_soa_to_aos<double, 16>), g, t, 0, stream, (const double *)b.base, b.stride, first, count, slots(b), d_aos);
+        else                hipLaunchKernelGGL((k_soa_to_aos<double, 12>), g, t, 0, stream, (const double *)b.base, b.stride, first, count, slots(b), d_aos);
     } else {
-        if (b.variant == 3) hipLaunchKernelGGL((k_soa_to_aos<float, 16>), g, t, 0, stream, (const float *)b.base, b.stride, b.n, d_aos);
-        else                hipLaunchKernelGGL((k_soa_to_aos<float, 12>), g, t, 0, stream, (const float *)b.base, b.stride, b.n, d_aos);
+        if (b.variant == 3) hipLaunchKernelGGL((k_soa_to_aos<float, 16>), g, t, 0, stream, (const float *)b.base, b.stride, first, count, slots(b), d_aos);
+        else                hipLaunchKernelGGL((k_soa_to_aos<float, 12>), g, t, 0, stream, (const float *)b.base, b.stride, first, count, slots(b), d_aos);
     }
     return hipGetLastError();
 }
+
+hipError_t launch_soa_to_aos(const BatchView &b, double *d_aos, hipStream_t stream) { return launch_soa_to_aos_range(b, 0, b.n, d_aos, stream); }
 
 hipError_t launch_init_feasible(const BatchView &b, const HostParams &hp, const double *d_pos0, const double *d_pos1,
                                 const double *d_pos2, hipStream_t stream)
 {
     RP_DISPATCH(b, hipLaunchKernelGGL((k_init_feasible<S, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                       (S *)b.base, b.stride, b.n, hp.accel_limit, d_pos0, d_pos1, d_pos2));
+                                       (S *)b.base, b.stride, b.n, hp.accel_limit, d_pos0, d_pos1, d_pos2,
+                                       b.scheduled ? (const uint32_t *)b.prob_of : (const uint32_t *)nullptr));
     return hipGetLastError();
 }
 
@@ -1241,37 +1231,22 @@ hipError_t launch_move_toward_feasibility(const BatchView &b, const HostParams &
     return hipGetLastError();
 }
 
-hipError_t launch_sample(const BatchView &b, double *d_pos66, double *d_acc4, hipStream_t stream)
+// ---- read-backs by problem index: a range [first, first + count) of problems, wherever they lie in the batch ----
+hipError_t launch_sample_range(const BatchView &b, size_t first, size_t count, double *d_pos66, double *d_acc4, hipStream_t stream)
 {
-    const size_t total = b.n * 70;
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_sample<S, V>), dim3(grid_for(total)), dim3(kBlock), 0, stream,
-                                       (const S *)b.base, b.stride, b.n, d_pos66, d_acc4));
+    if (count == 0) return hipSuccess;
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_sample<S, V>), dim3(grid_for(count * 70)), dim3(kBlock), 0, stream,
+                                       (const S *)b.base, b.stride, first, count, slots(b), d_pos66, d_acc4));
     return hipGetLastError();
 }
 
-// ---- ranges (the watched problem of the host plug-in): the same kernels on a window [first, first + count) ----
-static BatchView window(const BatchView &b, size_t first, size_t count)
-{
-    BatchView w = b;
-    w.base = (char *)b.base + first * storage_size(b.dtype);
-    w.n = count;
-    return w;
-}
-
-hipError_t launch_soa_to_aos_range(const BatchView &b, size_t first, size_t count, double *d_aos, hipStream_t stream)
-{
-    return launch_soa_to_aos(window(b, first, count), d_aos, stream);
-}
-
-hipError_t launch_sample_range(const BatchView &b, size_t first, size_t count, double *d_pos66, double *d_acc4, hipStream_t stream)
-{
-    return launch_sample(window(b, first, count), d_pos66, d_acc4, stream);
-}
+hipError_t launch_sample(const BatchView &b, double *d_pos66, double *d_acc4, hipStream_t stream) { return launch_sample_range(b, 0, b.n, d_pos66, d_acc4, stream); }
 
 hipError_t launch_constraint_table(const BatchView &b, const HostParams &hp, size_t first, size_t count, double *d_rows, hipStream_t stream)
 {
+    if (count == 0) return hipSuccess;
     RP_DISPATCH(b, hipLaunchKernelGGL((k_constraint_table<S, T, V>), dim3(grid_for(count)), dim3(kBlock), 0, stream,
-                                       (const S *)b.base, b.stride, first, count, make_kparams<T>(hp, V), d_rows));
+                                       (const S *)b.base, b.stride, first, count, slots(b), make_kparams<T>(hp, V), d_rows));
     return hipGetLastError();
 }
 

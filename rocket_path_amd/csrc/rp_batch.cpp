@@ -27,6 +27,7 @@ struct rp_batch {
     double *d_aos;            // lazily allocated n * state_len doubles
     double *d_pos;            // lazily allocated 3 * n doubles (set_problems staging)
     double *d_range;          // lazily allocated kRangeChunk * kRangeRow doubles: staging of the *_range read-backs
+    uint32_t *d_words;        // lazily allocated 2 n words: per-problem words gathered from batch order into problem order
     double ungated_steps;     // per-problem count of ungated steps since the last init
     unsigned long long *h_pinned;   // 72 pinned host words: [0,64) counter shards, [64,68) reduction: read-backs without pageable staging
     hipEvent_t events[8];
@@ -83,7 +84,12 @@ int reset_progress(rp_batch *b)
 {
     b->ungated_steps = 0.0;
     RP_HIP(rp::launch_clear_progress(b->view, b->stream));
-    RP_HIP(rp::launch_order(b->view, b->stream));     // every init path ends here: positions are final
+    return RP_OK;
+}
+
+int need_words(rp_batch *b)
+{
+    if (!b->d_words) RP_HIP(hipMalloc((void **)&b->d_words, 2 * b->view.n * sizeof(uint32_t)));
     return RP_OK;
 }
 
@@ -110,7 +116,7 @@ int need_aos(rp_batch *b)
 
 extern "C" {
 
-const char *rp_version(void) { return "rocket_path_amd 0.2 (gfx950)"; }
+const char *rp_version(void) { return "rocket_path_amd 0.3 (gfx950)"; }
 const char *rp_last_error(void) { return g_err; }
 
 const char *rp_status_string(int status)
@@ -183,6 +189,7 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     if ((b->view.stride / 512) % 2 == 0) b->view.stride += 512;
     if (const char *pad = getenv("RP_STRIDE_PAD")) b->view.stride += (size_t)atoi(pad) / 16 * 16;      // tuning probe only
     b->view.zero_end_vel = true;       // the state starts all-zero
+    b->view.scheduled = false;         // ... and identical problems lie in problem order
     const size_t fields = (size_t)rp::state_len(variant);
 
     hipError_t e = hipSuccess;
@@ -191,13 +198,13 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     if (e == hipSuccess) e = hipMalloc(&b->view.base, fields * b->view.stride * elem_size(dtype));
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.iters, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.status, n * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&b->view.order, n * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->view.slot_of, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->view.prob_of, n * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&b->view.counters, 128 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_scratch, (4096 + 4) * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_pinned, 72 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemsetAsync(b->view.base, 0, fields * b->view.stride * elem_size(dtype), b->stream);
     if (e == hipSuccess) e = rp::launch_clear_progress(b->view, b->stream);
-    if (e == hipSuccess) e = rp::launch_order(b->view, b->stream);
     if (e != hipSuccess) {
         const int code = fail(e == hipErrorOutOfMemory ? RP_ERR_NOMEM : RP_ERR_DEVICE, "rp_batch_create: %s", hipGetErrorString(e));
         rp_batch_destroy(b);
@@ -216,7 +223,9 @@ int rp_batch_destroy(rp_batch *b)
     if (b->view.base) (void)hipFree(b->view.base);
     if (b->view.iters) (void)hipFree(b->view.iters);
     if (b->view.status) (void)hipFree(b->view.status);
-    if (b->view.order) (void)hipFree(b->view.order);
+    if (b->view.slot_of) (void)hipFree(b->view.slot_of);
+    if (b->view.prob_of) (void)hipFree(b->view.prob_of);
+    if (b->d_words) (void)hipFree(b->d_words);
     if (b->view.counters) (void)hipFree(b->view.counters);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
@@ -298,6 +307,7 @@ int rp_batch_init_default(rp_batch *b)
     s[3 + m + 0] = 0.0; s[3 + m + 1] = 0.0; s[3 + m + 2] = 200.0; s[3 + m + 3] = 400.0; s[3 + m + 4] = 0.0;
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
     b->view.zero_end_vel = true;
+    b->view.scheduled = false;         // identical problems: nothing to schedule
     return reset_progress(b);
 }
 
@@ -311,6 +321,7 @@ int rp_batch_init_stuck(rp_batch *b)
                           0.0, 0.0, 350.0, 400.0, 0.0};
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
     b->view.zero_end_vel = true;
+    b->view.scheduled = false;
     return reset_progress(b);
 }
 
@@ -318,6 +329,9 @@ int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double
 {
     RP_NEED(b);
     if (!d_pos0 || !d_pos1 || !d_pos2) return fail(RP_ERR_INVALID, "null position array");
+    // where each problem goes (scheduled order, ip_kernels.hip), then the feasible start of the problem at each position
+    RP_HIP(rp::launch_schedule(b->view, d_pos0, d_pos1, d_pos2, 1, b->stream));
+    b->view.scheduled = true;
     RP_HIP(rp::launch_init_feasible(b->view, b->params, d_pos0, d_pos1, d_pos2, b->stream));
     b->view.zero_end_vel = true;       // the feasible-start rule sets vel0 = vel2 = 0
     return reset_progress(b);
@@ -329,7 +343,7 @@ int rp_batch_restart(rp_batch *b)
     RP_HIP(rp::launch_restart_feasible(b->view, b->params, b->stream));
     b->view.zero_end_vel = true;
     b->ungated_steps = 0.0;
-    RP_HIP(rp::launch_clear_progress(b->view, b->stream));      // the positions have not changed: the scheduling order stays valid
+    RP_HIP(rp::launch_clear_progress(b->view, b->stream));      // the positions have not changed: the scheduled order stays as it is
     return RP_OK;
 }
 
@@ -362,6 +376,11 @@ int rp_batch_set_state(rp_batch *b, const double *aos)
         b->view.zero_end_vel = zero;
     }
     RP_HIP(hipMemcpyAsync(b->d_aos, aos, bytes, hipMemcpyHostToDevice, b->stream));
+    {   // schedule by the positions in the rows (columns pos0, pos1, pos2 of the reference's enum), then scatter the rows
+        const size_t cb = 3 + (size_t)rp::num_constraints(b->view.variant);
+        RP_HIP(rp::launch_schedule(b->view, b->d_aos + cb + 0, b->d_aos + cb + 2, b->d_aos + cb + 3, M, b->stream));
+        b->view.scheduled = true;
+    }
     RP_HIP(rp::launch_aos_to_soa(b->view, b->d_aos, b->stream));
     st = reset_progress(b);
     if (st != RP_OK) return st;
@@ -430,10 +449,17 @@ int rp_batch_step_counted(rp_batch *b, int k, uint32_t *feas_halvings, uint32_t 
     if (b->params.mu_mode != 0) return fail(RP_ERR_UNSUPPORTED, "the counted step exists for the reference's mu mode only");
     const size_t n = b->view.n;
     uint32_t *d = nullptr;
-    RP_HIP(hipMalloc((void **)&d, 2 * n * sizeof(uint32_t)));
+    RP_HIP(hipMalloc((void **)&d, 4 * n * sizeof(uint32_t)));
     hipError_t e = rp::launch_steps_counted(b->view, b->params, k, d, d + n, b->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(feas_halvings, d, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(resid_halvings, d + n, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream);
+    const uint32_t *out_f = d, *out_r = d + n;
+    if (b->view.scheduled) {      // the kernel counts per position: bring the counts into problem order
+        if (e == hipSuccess) e = rp::launch_gather_u32(b->view, d, d + 2 * n, b->stream);
+        if (e == hipSuccess) e = rp::launch_gather_u32(b->view, d + n, d + 3 * n, b->stream);
+        out_f = d + 2 * n;
+        out_r = d + 3 * n;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(feas_halvings, out_f, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(resid_halvings, out_r, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RP_ERR_DEVICE, "rp_batch_step_counted: %s", hipGetErrorString(e));
@@ -484,8 +510,17 @@ int rp_batch_get_iters(rp_batch *b, int32_t *iters, uint32_t *status)
 {
     RP_NEED(b);
     const size_t n = b->view.n;
-    if (iters) RP_HIP(hipMemcpyAsync(iters, b->view.iters, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
-    if (status) RP_HIP(hipMemcpyAsync(status, b->view.status, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    const uint32_t *src_it = reinterpret_cast<const uint32_t *>(b->view.iters), *src_st = b->view.status;
+    if (b->view.scheduled) {      // the words lie in batch order
+        int st = need_words(b);
+        if (st != RP_OK) return st;
+        if (iters) RP_HIP(rp::launch_gather_u32(b->view, src_it, b->d_words, b->stream));
+        if (status) RP_HIP(rp::launch_gather_u32(b->view, src_st, b->d_words + n, b->stream));
+        src_it = b->d_words;
+        src_st = b->d_words + n;
+    }
+    if (iters) RP_HIP(hipMemcpyAsync(iters, src_it, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    if (status) RP_HIP(hipMemcpyAsync(status, src_st, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     RP_HIP(hipStreamSynchronize(b->stream));
     if (iters && b->ungated_steps > 0) {
         const int32_t add = (int32_t)b->ungated_steps;
@@ -638,6 +673,20 @@ int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr)
         const int iv0 = 3 + rp::num_constraints(b->view.variant) + 1, iv2 = iv0 + 3;
         if (field == iv0 || field == iv2) b->view.zero_end_vel = false;
     }
+    return RP_OK;
+}
+
+int rp_batch_slot_map(rp_batch *b, uint32_t *slot_of_problem)
+{
+    RP_NEED(b);
+    if (!slot_of_problem) return fail(RP_ERR_INVALID, "null output");
+    const size_t n = b->view.n;
+    if (!b->view.scheduled) {
+        for (size_t i = 0; i < n; ++i) slot_of_problem[i] = (uint32_t)i;
+        return RP_OK;
+    }
+    RP_HIP(hipMemcpyAsync(slot_of_problem, b->view.slot_of, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    RP_HIP(hipStreamSynchronize(b->stream));
     return RP_OK;
 }
 

@@ -140,9 +140,14 @@ def test_field_ptr_to_an_end_velocity_selects_the_general_kernels(oracle):
     v2 = np.linspace(0.04, -0.04, n)
     with rp.Batch(n) as b:
         b.set_problems(p0, p1, p2)
+        # a field's elements lie in batch order: problem i at position slot_map()[i]
+        slot = b.slot_map()
+        assert np.array_equal(np.sort(slot), np.arange(n)) and not np.array_equal(slot, np.arange(n))
         for field, vals in ((12, v0), (15, v2)):
             ptr = b.field_ptr(field)
-            assert hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(vals.ctypes.data), ctypes.c_size_t(n * 8), 1) == 0
+            in_batch_order = np.empty(n)
+            in_batch_order[slot] = vals
+            assert hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(in_batch_order.ctypes.data), ctypes.c_size_t(n * 8), 1) == 0
         st0 = b.get_state()
         assert np.array_equal(st0[:, 12], v0) and np.array_equal(st0[:, 15], v2)
         b.step(5)
@@ -292,3 +297,71 @@ def test_two_rank_bench_rehearsal_on_one_device_covers_the_whole_batch():
     g = line["config"]["final_summary"]
     assert g["n_converged"] == 2 * per and g["total_steps"] == r["total_steps"]
     assert g["max_gap"] == r["max_gap"] and g["max_residual_sq"] == r["max_residual_sq"]
+
+
+# ---- the scheduled order inside the batch (ip_kernels.hip, k_schedule_windows): invisible at the boundary ----
+
+def _ratio(p0, p1, p2):
+    d0, d1 = np.abs(p1 - p0), np.abs(p2 - p1)
+    return np.minimum(d0, d1) / np.maximum(d0, d1)
+
+
+@pytest.mark.parametrize("n", [1, 63, 4096, 3 * 4096 + 77])
+def test_scheduled_order_sorts_each_window_by_the_segment_ratio(n):
+    p0, p1, p2 = rp.problems.generate(4242, 0, n, rp.problems.DIST_NON_MONOTONE)
+    with rp.Batch(n) as b:
+        assert np.array_equal(b.slot_map(), np.arange(n))            # before any positions: problem order
+        b.set_problems(p0, p1, p2)
+        slot = b.slot_map()
+        assert np.array_equal(np.sort(slot), np.arange(n))           # a permutation ...
+        assert np.array_equal(slot // 4096, np.arange(n) // 4096)    # ... within each window of 4,096 problems
+        prob_of = np.empty(n, dtype=np.int64)
+        prob_of[slot] = np.arange(n)
+        q = np.floor(_ratio(p0, p1, p2)[prob_of] * 1048575.0)        # the kernel's 20-bit key
+        for w in range(0, n, 4096):
+            assert np.all(np.diff(q[w:w + 4096]) >= 0), w
+        b.init_default()
+        assert np.array_equal(b.slot_map(), np.arange(n))            # identical problems: problem order again
+
+
+def test_results_do_not_depend_on_where_a_problem_lies_in_the_batch():
+    # the same problems handed over in two different orders land in different lanes of different waves; every problem's
+    # iterates, step count and status must be the same bit for bit
+    n = 5 * 4096 + 301
+    p0, p1, p2 = rp.problems.generate(99, 0, n, rp.problems.DIST_MONOTONE)
+    shuffle = np.random.default_rng(3).permutation(n)
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        b.set_problems(p0[shuffle].copy(), p1[shuffle].copy(), p2[shuffle].copy())
+        assert not np.array_equal(a.slot_map()[shuffle], b.slot_map())
+        assert np.array_equal(a.get_state()[shuffle], b.get_state())
+        a.solve(1e-8, 200, 0)
+        b.solve(1e-8, 200, 0)
+        assert np.array_equal(a.get_state()[shuffle], b.get_state())
+        ia, sa = a.get_iters()
+        ib, sb = b.get_iters()
+        assert np.array_equal(ia[shuffle], ib) and np.array_equal(sa[shuffle], sb)
+        fa, ra = a.step_counted(2)
+        fb, rb = b.step_counted(2)
+        assert np.array_equal(fa[shuffle], fb) and np.array_equal(ra[shuffle], rb)
+        pa, aa = a.sample()
+        pb, ab = b.sample()
+        assert np.array_equal(pa[shuffle], pb) and np.array_equal(aa[shuffle], ab)
+        gap_a, table_a = a.constraints_range(0, n)
+        for first, count in ((0, 3), (4090, 12), (n - 5, 5)):
+            gap_b, table_b = b.constraints_range(first, count)
+            assert np.array_equal(gap_b, gap_a[shuffle][first:first + count])
+            assert np.array_equal(table_b, table_a[shuffle][first:first + count])
+
+
+@pytest.mark.parametrize("variant,dtype", [(rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F32_STATE)])
+def test_set_state_round_trips_in_problem_order(variant, dtype):
+    n = 2 * 4096 + 9
+    m = 16 if variant == rp.VARIANT_F3 else 12
+    rng = np.random.default_rng(17)
+    aos = rng.uniform(0.5, 2.0, (n, m)).astype(np.float32).astype(np.float64)      # exactly representable in fp32 state too
+    with rp.Batch(n, variant, dtype) as b:
+        b.set_state(aos)
+        assert not np.array_equal(b.slot_map(), np.arange(n))        # scheduled by the positions in the rows
+        assert np.array_equal(b.get_state(), aos)
+        assert np.array_equal(b.get_state_range(4000, 200), aos[4000:4200])
