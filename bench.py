@@ -18,7 +18,7 @@ N > 1: one process per GPU, rank r owns the contiguous shard r of the N x 1,048,
 all-reduce over RCCL.
 
 Printed by rank 0: ONE JSON line (contract in the task statement).  `roofline` prices the timed kernel
-(k_solve_tiled<double, F3>, the fused gated solve) against the roof that binds it, the fp64 vector ALU, and
+(k_solve_chunks<double, F3>, the fused gated solve) against the roof that binds it, the fp64 vector ALU, and
 carries the SURVEY 8d algorithmic-HBM figure as the labelled secondary `hbm_algorithmic` (a fused launch moves each
 state across HBM once per solve, not once per step).  `cpu_baseline` = the oracle port on the host cores (N = 1
 only).  Labelled extras: `per_step_launch` (one launch per Newton step, the form in which the bytes really cross
@@ -240,7 +240,7 @@ def main():
 
     steps_per_launch = steps_local / max(K, 1)
     alg_gbs = B_ALG_F3 * steps_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = profile_number(PROFILE_TAG + "_hbm_traffic.json", "k_solve_tiled_f3_f64", "hbm_bytes_per_launch")
+    traffic, traffic_src = profile_number(PROFILE_TAG + "_hbm_traffic.json", "k_solve_chunks_f3_f64", "hbm_bytes_per_launch")
     flop_per_step, flop_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_flop_per_gated_newton_step")      # the gated kernel itself
     if flop_per_step is None:
         flop_per_step, flop_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_flop_per_newton_step")
@@ -287,13 +287,13 @@ def main():
         # its gate and is fp64-VALU bound (VALU busy ~1.0 across the resident waves): flop per Newton step from the
         # rocprofv3 SQ counters (2 x FMA + MUL + ADD + TRANS wave-instructions of an all-lanes-active launch, per lane-step).
         "roofline": {
-            "bound": "fp64_valu", "kernel": "k_solve_tiled<double, double, F3, gated> (fused gated solve)",
+            "bound": "fp64_valu", "kernel": "k_solve_chunks<double, double, F3> (fused gated solve, one 64-problem chunk of the scheduled order per wave)",
             "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
             "flop_per_newton_step": flop_per_step, "flop_per_newton_step_source": flop_src,
             "avg_launch_ms": kernel_ms, "newton_steps_per_launch": steps_per_launch,
             "traffic": traffic, "traffic_source": traffic_src,
             "note": "flop actually executed by the timed kernel (SQ counters of the same kernel on identical problems, per lane-step); "
-                    "idle lane-steps of the gated solve (~5 %) are not counted; traffic = HBM bytes per launch from FETCH_SIZE (x2, "
+                    "idle lane-steps of the gated solve (~1 % in the scheduled order) are not counted; traffic = HBM bytes per launch from FETCH_SIZE (x2, "
                     "calibrated) + WRITE_SIZE: each state crosses HBM once per solve.  A step got cheaper in round 2 (609 -> 533 flop in "
                     "the fixed-step kernels, 431 in the gated one, which carries its residual sums), so this fraction FALLS while steps/s "
                     "rise: the vector ALU is issue-saturated either way (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.32 x 3 resident waves)",

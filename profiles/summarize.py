@@ -68,23 +68,32 @@ def alias(key, prefix, expected):
         out[key] = dict(out[hit[0]], kernel=hit[0], expected=expected)
 
 
-alias("k_solve_tiled_f3_f64", "k_solve_tiled<double, double, 3, true",
-      "zero-end-velocity instantiation: (14x8 + 4 + 4 + 2) B read + (11x8 + 4 + 4) B written per problem = 127.9 + 100.7 MB at n = 1,048,576")
+alias("k_solve_chunks_f3_f64", "k_solve_chunks<double, double, 3, false, true",
+      "zero-end-velocity instantiation: (14x8 + 4 + 4) B read + (11x8 + 4 + 4) B written per problem = 125.8 + 100.7 MB at n = 1,048,576")
 alias("k_newton_stream16_f3_f64", "k_newton_stream16<double, double, 3, true", "14x8 B read + 11x8 B written per problem = 117.4 + 92.3 MB")
 alias("k_newton_stream16_f4_f32", "k_newton_stream16<float, float, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
 alias("k_newton_stream16_f4_f32state", "k_newton_stream16<float, double, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
 alias("k_steps_regrouped_f4_f32", "k_steps_regrouped<float, float, 4", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per 50-step launch")
 alias("k_steps_regrouped_f4_f32state", "k_steps_regrouped<float, double, 4", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per 50-step launch")
-alias("k_solve_tiled_f4_f32", "k_solve_tiled<float, float, 4, false", "(10x4 + 2) B read + 7x4 B written per problem = 44.0 + 29.4 MB per 50-step launch")
-alias("k_solve_tiled_f4_f32state", "k_solve_tiled<float, double, 4, false", "(10x4 + 2) B read + 7x4 B written per problem = 44.0 + 29.4 MB per 50-step launch")
+alias("k_steps_tiled_f3_f64", "k_steps_tiled<double, double, 3, true", "14x8 B read + 11x8 B written per problem = 117.4 + 92.3 MB per launch")
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag), "w"), indent=1)
 
+def real_grid(name):
+    """Work-items of the 1 Mi-problem launch of a Newton kernel of the probe: one lane per problem in the gated kernel, two
+    problems per lane (tile rounds / 16-byte accesses) in the others."""
+    return N if name.startswith("k_solve_chunks") else N // 2
+
+
 sq = {}
+ident = {}
 for d in sq_dirs:
-    for k, cs in counters(d, grid=N // 2).items():      # the 1 Mi-problem launches: 524,288 work-items in every Newton kernel of the probe
-        name = short(k)
-        if name.startswith(("k_newton", "k_solve")):
-            sq.setdefault(name, {}).update(cs)
+    for grid in (N, N // 2):
+        for k, cs in counters(d, grid=grid).items():
+            name = short(k)
+            if name.startswith(("k_newton", "k_solve", "k_steps")) and grid == real_grid(name):
+                sq.setdefault(name, {}).update(cs)
+            elif name.startswith("k_solve_chunks<double, double, 3, false, true") and grid == N // 2:
+                ident.update(cs)      # the gated kernel on 524,288 identical default problems (pmc_probe.py)
 for name, c in sq.items():
     if "SQ_WAVES" in c and "SQ_INSTS_VALU" in c:
         c["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
@@ -94,7 +103,7 @@ for name, c in sq.items():
 lane_steps = float(PROBE_STEPS) * N
 top = {}
 for name, c in sq.items():
-    if not name.startswith("k_solve_tiled") or ", false, false, true>" not in name:
+    if not name.startswith("k_steps_tiled") or not name.endswith(", true>"):
         continue
     f64 = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0)
                   + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) / lane_steps
@@ -103,27 +112,23 @@ for name, c in sq.items():
     c["flop_f64_per_lane_step"], c["flop_f32_per_lane_step"] = f64, f32
     if "SQ_INSTS_VALU" in c:
         c["valu_insts_per_lane_step"] = 64.0 * c["SQ_INSTS_VALU"] / lane_steps
-    if name.startswith("k_solve_tiled<double, double, 3"):
+    if name.startswith("k_steps_tiled<double, double, 3"):
         top["_flop_per_newton_step"] = f64
-    elif name.startswith("k_solve_tiled<float, float, 4"):
+    elif name.startswith("k_steps_tiled<float, float, 4"):
         top["_flop_per_f4_step_f32"] = f32 + f64
-    elif name.startswith("k_solve_tiled<float, double, 4"):
+    elif name.startswith("k_steps_tiled<float, double, 4"):
         top["_flop_per_f4_step_f32state"] = f64
-# the gated kernel on 524,288 identical default problems (pmc_probe.py): 15 steps per problem, no idle lanes
-ident = {}
-for d in sq_dirs:
-    for k, cs in counters(d, grid=(N // 2) // 2).items():      # 512 problems per 256-thread block
-        if short(k).startswith("k_solve_tiled<double, double, 3, true"):
-            ident.update(cs)
+# the gated kernel on identical problems: 15 steps per problem, no idle lanes
+GATED = "k_solve_chunks<double, double, 3, false, true, 0>"
 if "SQ_INSTS_VALU_FMA_F64" in ident:
     ls = 15.0 * (N // 2)
     ident["flop_f64_per_lane_step"] = 64.0 * (2 * ident["SQ_INSTS_VALU_FMA_F64"] + ident["SQ_INSTS_VALU_MUL_F64"] + ident["SQ_INSTS_VALU_ADD_F64"]
                                              + ident["SQ_INSTS_VALU_TRANS_F64"]) / ls
     if "SQ_INSTS_VALU" in ident:
         ident["valu_insts_per_lane_step"] = 64.0 * ident["SQ_INSTS_VALU"] / ls
-    sq["k_solve_tiled<double, double, 3, true, false, true> on identical problems"] = ident
+    sq[GATED + " on identical problems"] = ident
     top["_flop_per_gated_newton_step"] = ident["flop_f64_per_lane_step"]
-gated_real = sq.get("k_solve_tiled<double, double, 3, true, false, true>", {})
+gated_real = sq.get(GATED, {})
 if "SQ_INSTS_VALU" in gated_real:
     top["_valu_wave_insts_per_gated_launch"] = gated_real["SQ_INSTS_VALU"]      # the benchmark's launch itself (idle lanes included)
 sq.update(top)

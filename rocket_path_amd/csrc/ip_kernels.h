@@ -20,7 +20,7 @@ struct BatchView {
     bool zero_end_vel;     // vel0X == vel2X == 0 for every problem (true after every init the reference has; see Prob in ip_core.h)
     int32_t *iters;        // gated Newton steps taken per problem
     uint32_t *status;      // RP_ST_* bits per problem
-    uint32_t *slot_of;     // scheduled order (k_schedule_windows): problem index -> position in the batch ...
+    uint32_t *slot_of;     // scheduled order (schedule.hip): problem index -> position in the batch ...
     uint32_t *prob_of;     // ... and position -> problem index; both n words, meaningful while `scheduled`
     bool scheduled;        // false: the problems lie in problem order (identical problems of initDefault / initStuck)
     unsigned long long *counters;   // 128 words: [0,64) shards of "problems still open after the last gated launch", [64,128) shards of gated steps executed
@@ -59,8 +59,11 @@ hipError_t launch_restart_feasible(const BatchView &b, const HostParams &hp, hip
 hipError_t launch_init_const(const BatchView &b, const double *host_state /* state_len values */, hipStream_t stream);
 hipError_t launch_nudge(const BatchView &b, int field, double delta, hipStream_t stream);
 hipError_t launch_clear_progress(const BatchView &b, hipStream_t stream);
-// compute the scheduled order (slot_of / prob_of) from positions given as three strided double arrays in problem order
-hipError_t launch_schedule(const BatchView &b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride, hipStream_t stream);
+// compute the scheduled order (slot_of / prob_of; schedule.hip) from positions given as three strided double arrays in
+// problem order; d_scratch: schedule_scratch_bytes(n) bytes of device memory
+hipError_t schedule_scratch_bytes(size_t n, size_t *bytes);
+hipError_t launch_schedule(const BatchView &b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride,
+                           void *d_scratch, size_t scratch_bytes, hipStream_t stream);
 // d_dst[problem] = d_src[position of that problem] for per-problem words kept in batch order (requires b.scheduled)
 hipError_t launch_gather_u32(const BatchView &b, const uint32_t *d_src, uint32_t *d_dst, hipStream_t stream);
 

@@ -8,9 +8,9 @@
 // channel).  One Newton step reads 16 and writes 11 fields (F3): 216 B per problem per step, the
 // algorithmic traffic of SURVEY.md 8d; the kernels instantiated for zero end velocities read 14.
 //
-// Within the batch the problems lie in SCHEDULED order (k_schedule_windows, run when positions are set): every window of
-// 4,096 consecutive problems is sorted by its segment-length ratio min|dX| / max|dX|, which predicts the gated step count
-// (problems with similar segments take longest).  slot_of[] / prob_of[] map problem index <-> position; only the kernels at
+// Within the batch the problems lie in SCHEDULED order (schedule.hip, run when positions are set): sorted by what predicts
+// their gated step count, the segment-length ratio min|dX| / max|dX| (64 classes; similar segments take longest) and,
+// within a class, the longer segment's length.  slot_of[] / prob_of[] map problem index <-> position; only the kernels at
 // the ABI boundary (state in / out, read-backs by problem index) look at them, the Newton kernels walk positions.
 //
 // Launch shapes, all sharing the per-lane step of ip_core.h:
@@ -39,10 +39,6 @@ namespace rp {
 namespace {
 
 constexpr int kBlock = 256;
-// The scheduled order: windows of kWindow problems, each sorted; a chunk = 64 consecutive positions = one wave of the gated solve.
-constexpr int kWindow = 4096;
-constexpr int kChunksPerWindow = kWindow / 64;
-
 // once-per-launch global accesses (state in, results out): nontemporal, they are never re-read through the caches
 #if !defined(RP_STREAM_PLAIN) && !defined(RP_TILE_PLAIN)
 template <typename S> __device__ __forceinline__ S ld_once(const S *p) { return __builtin_nontemporal_load(p); }
@@ -188,7 +184,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
 // stored as full coalesced segments with no LDS and no block barrier in between.  With one wave per block the hardware
 // dispatcher IS the work queue: a wave that finishes early frees its slot for the next chunk, so the tail of the grid is
 // one chunk long instead of one 512-problem tile (which cost 11 % at 1 Mi problems: 2,048 tiles over 768 slots), and
-// the blocks are numbered so that the longest chunks (highest ratio rank, one from every window in turn) start first.
+// the blocks walk the order from its end, so the longest chunks start first.
 // Which lane solves which problem changes nothing in any problem's result (lanes never interact); a stale order
 // (positions nudged after it was computed) is merely a less effective schedule.
 // (mu_mode 1 carries the split direction: ~210 VGPRs, two waves per SIMD)
@@ -199,9 +195,8 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;   // first constant field: pos0, vel0, pos1, pos2, vel2
-    const unsigned windows = (unsigned)((n + kWindow - 1) / kWindow);      // gridDim.x == windows * kChunksPerWindow
-    const unsigned rank = kChunksPerWindow - 1 - blockIdx.x / windows, window = blockIdx.x % windows;
-    const size_t i = (size_t)window * kWindow + (size_t)rank * 64 + threadIdx.x;
+    const unsigned chunk = gridDim.x - 1 - blockIdx.x;      // the scheduled order ends with the longest problems: they start first
+    const size_t i = (size_t)chunk * 64 + threadIdx.x;
 
     int it = 0;
     uint32_t st = 0;
@@ -211,7 +206,7 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
         st = status[i];
         active = (st & (RP_ST_CONVERGED | RP_ST_MAXITER | RP_ST_STALLED)) == 0;
     }
-    if (__ballot(active) == 0) return;      // past the end of a ragged window, or a chunk that finished in an earlier launch
+    if (__ballot(active) == 0) return;      // a chunk that finished in an earlier launch
     int steps_here = 0;
     bool still_open = false;
 
@@ -745,50 +740,6 @@ k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ slot
     if (i < n) dst[i] = src[slot_of[i]];
 }
 
-// ---------------------------------------------------------------------------------------
-// The scheduled order.  One 1,024-thread block per window of kWindow problems: key = the segment-length ratio
-// min|dX| / max|dX| quantised to 20 bits, tie-broken by the problem's index in the window (so the order is a pure function
-// of the positions), bitonic sort in LDS, ascending: the problems expected to take longest end up in the window's last
-// chunks.  Positions come as three strided double arrays (separate arrays: pstride 1; rows of an AoS state: pstride M).
-__global__ void __launch_bounds__(1024)
-k_schedule_windows(const double *__restrict__ pos0, const double *__restrict__ pos1, const double *__restrict__ pos2, size_t pstride,
-                   size_t n, uint32_t *__restrict__ slot_of, uint32_t *__restrict__ prob_of)
-{
-    __shared__ uint32_t key[kWindow];
-    const int tid = threadIdx.x;
-    const size_t first = (size_t)blockIdx.x * kWindow;
-    const int count = (n - first < (size_t)kWindow) ? (int)(n - first) : kWindow;
-    for (int j = tid; j < kWindow; j += 1024) {
-        uint32_t q = 0xFFFFFFFFu;      // padding sorts behind every problem
-        if (j < count) {
-            const size_t at = (first + j) * pstride;
-            const double d0 = __builtin_fabs(pos1[at] - pos0[at]), d1 = __builtin_fabs(pos2[at] - pos1[at]);
-            const double lo = d0 < d1 ? d0 : d1, hi = d0 < d1 ? d1 : d0;
-            const double r = lo / hi * 1048575.0;
-            const uint32_t bucket = (r >= 0.0 && r < 1048575.0) ? (uint32_t)r : 1048574u;      // equal lengths / NaN -> last
-            q = (bucket << 12) | (uint32_t)j;
-        }
-        key[j] = q;
-    }
-    __syncthreads();
-    for (int size = 2; size <= kWindow; size <<= 1) {
-        for (int dist = size >> 1; dist > 0; dist >>= 1) {
-            for (int t = tid; t < kWindow / 2; t += 1024) {
-                const int lo = ((t / dist) * 2 * dist) + (t % dist), hi = lo + dist;
-                const bool ascending = (lo & size) == 0;
-                const uint32_t a = key[lo], b = key[hi];
-                if ((a > b) == ascending) { key[lo] = b; key[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
-    for (int j = tid; j < count; j += 1024) {
-        const uint32_t local = key[j] & 0xFFFu;
-        prob_of[first + j] = (uint32_t)(first + local);
-        slot_of[first + local] = (uint32_t)(first + j);
-    }
-}
-
 // Feasible start (build-defined): vel1 = 0, t_i = (3.5/sqrt 12) sqrt(6 |dX_i| / L),
 // multipliers 1, vel0 = vel2 = 0.  Computed in double, stored in the compute type.
 template <typename T, int VARIANT>
@@ -1097,8 +1048,7 @@ hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k,
 // the gated solve: up to k gated steps per problem, one 64-problem chunk of the scheduled order per single-wave block
 static hipError_t launch_chunks(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream)
 {
-    const unsigned windows = (unsigned)((b.n + kWindow - 1) / kWindow);
-    const dim3 grid(windows * kChunksPerWindow), block(64);
+    const dim3 grid((unsigned)((b.n + 63) / 64)), block(64);
     if (hp.mu_mode == 1)
         RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, true, Z, 1>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
                                                  make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters));
@@ -1123,14 +1073,6 @@ hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double 
     if (b.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(kShards), 0, stream, b.counters);
     return launch_chunks(b, hp, k, gap_tol, max_iter, stream);
-}
-
-hipError_t launch_schedule(const BatchView &b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride, hipStream_t stream)
-{
-    if (b.n == 0) return hipSuccess;
-    const unsigned windows = (unsigned)((b.n + kWindow - 1) / kWindow);
-    hipLaunchKernelGGL(k_schedule_windows, dim3(windows), dim3(1024), 0, stream, d_pos0, d_pos1, d_pos2, pstride, b.n, b.slot_of, b.prob_of);
-    return hipGetLastError();
 }
 
 hipError_t launch_gather_u32(const BatchView &b, const uint32_t *d_src, uint32_t *d_dst, hipStream_t stream)

@@ -28,6 +28,8 @@ struct rp_batch {
     double *d_pos;            // lazily allocated 3 * n doubles (set_problems staging)
     double *d_range;          // lazily allocated kRangeChunk * kRangeRow doubles: staging of the *_range read-backs
     uint32_t *d_words;        // lazily allocated 2 n words: per-problem words gathered from batch order into problem order
+    void *d_sched;            // lazily allocated scratch of the scheduling sort (schedule.hip), sched_bytes bytes
+    size_t sched_bytes;
     double ungated_steps;     // per-problem count of ungated steps since the last init
     unsigned long long *h_pinned;   // 72 pinned host words: [0,64) counter shards, [64,68) reduction: read-backs without pageable staging
     hipEvent_t events[8];
@@ -84,6 +86,18 @@ int reset_progress(rp_batch *b)
 {
     b->ungated_steps = 0.0;
     RP_HIP(rp::launch_clear_progress(b->view, b->stream));
+    return RP_OK;
+}
+
+// the scheduled order from positions given as three strided double arrays in problem order (device memory)
+int schedule(rp_batch *b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride)
+{
+    if (!b->d_sched) {
+        RP_HIP(rp::schedule_scratch_bytes(b->view.n, &b->sched_bytes));
+        RP_HIP(hipMalloc(&b->d_sched, b->sched_bytes));
+    }
+    RP_HIP(rp::launch_schedule(b->view, d_pos0, d_pos1, d_pos2, pstride, b->d_sched, b->sched_bytes, b->stream));
+    b->view.scheduled = true;
     return RP_OK;
 }
 
@@ -167,6 +181,7 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     if (dtype != RP_DTYPE_F64 && dtype != RP_DTYPE_F32 && dtype != RP_DTYPE_F32_STATE)
         return fail(RP_ERR_INVALID, "dtype %d (want 0 = f64, 1 = f32 or 2 = f32 state with f64 arithmetic)", dtype);
     if (n == 0) return fail(RP_ERR_INVALID, "empty batch");
+    if (n > 0x7fffffffu) return fail(RP_ERR_INVALID, "batch of %zu problems (at most 2^31 - 1 per batch; shard larger jobs)", n);
     int count = 0;
     int st = rp_device_count(&count);
     if (st != RP_OK || count == 0) return fail(RP_ERR_NO_DEVICE, "no HIP device visible; the interior-point path runs on the GPU only");
@@ -226,6 +241,7 @@ int rp_batch_destroy(rp_batch *b)
     if (b->view.slot_of) (void)hipFree(b->view.slot_of);
     if (b->view.prob_of) (void)hipFree(b->view.prob_of);
     if (b->d_words) (void)hipFree(b->d_words);
+    if (b->d_sched) (void)hipFree(b->d_sched);
     if (b->view.counters) (void)hipFree(b->view.counters);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
@@ -330,8 +346,8 @@ int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double
     RP_NEED(b);
     if (!d_pos0 || !d_pos1 || !d_pos2) return fail(RP_ERR_INVALID, "null position array");
     // where each problem goes (scheduled order, ip_kernels.hip), then the feasible start of the problem at each position
-    RP_HIP(rp::launch_schedule(b->view, d_pos0, d_pos1, d_pos2, 1, b->stream));
-    b->view.scheduled = true;
+    int st = schedule(b, d_pos0, d_pos1, d_pos2, 1);
+    if (st != RP_OK) return st;
     RP_HIP(rp::launch_init_feasible(b->view, b->params, d_pos0, d_pos1, d_pos2, b->stream));
     b->view.zero_end_vel = true;       // the feasible-start rule sets vel0 = vel2 = 0
     return reset_progress(b);
@@ -378,8 +394,8 @@ int rp_batch_set_state(rp_batch *b, const double *aos)
     RP_HIP(hipMemcpyAsync(b->d_aos, aos, bytes, hipMemcpyHostToDevice, b->stream));
     {   // schedule by the positions in the rows (columns pos0, pos1, pos2 of the reference's enum), then scatter the rows
         const size_t cb = 3 + (size_t)rp::num_constraints(b->view.variant);
-        RP_HIP(rp::launch_schedule(b->view, b->d_aos + cb + 0, b->d_aos + cb + 2, b->d_aos + cb + 3, M, b->stream));
-        b->view.scheduled = true;
+        st = schedule(b, b->d_aos + cb + 0, b->d_aos + cb + 2, b->d_aos + cb + 3, M);
+        if (st != RP_OK) return st;
     }
     RP_HIP(rp::launch_aos_to_soa(b->view, b->d_aos, b->stream));
     st = reset_progress(b);

@@ -299,27 +299,29 @@ def test_two_rank_bench_rehearsal_on_one_device_covers_the_whole_batch():
     assert g["max_gap"] == r["max_gap"] and g["max_residual_sq"] == r["max_residual_sq"]
 
 
-# ---- the scheduled order inside the batch (ip_kernels.hip, k_schedule_windows): invisible at the boundary ----
+# ---- the scheduled order inside the batch (csrc/schedule.hip): invisible at the boundary ----
 
-def _ratio(p0, p1, p2):
+def _schedule_key(p0, p1, p2):
+    """schedule.hip's key: ratio class (6 bits) : top 26 bits of the longer segment's float pattern."""
     d0, d1 = np.abs(p1 - p0), np.abs(p2 - p1)
-    return np.minimum(d0, d1) / np.maximum(d0, d1)
+    lo, hi = np.minimum(d0, d1), np.maximum(d0, d1)
+    r = lo / hi * 64.0
+    cls = np.where((r >= 0.0) & (r < 64.0), np.floor(r), 63).astype(np.uint64)
+    bits = hi.astype(np.float32).view(np.uint32).astype(np.uint64) >> np.uint64(5)
+    return (cls << np.uint64(26)) | bits
 
 
 @pytest.mark.parametrize("n", [1, 63, 4096, 3 * 4096 + 77])
-def test_scheduled_order_sorts_each_window_by_the_segment_ratio(n):
+def test_scheduled_order_is_the_stable_sort_by_ratio_class_and_length(n):
     p0, p1, p2 = rp.problems.generate(4242, 0, n, rp.problems.DIST_NON_MONOTONE)
     with rp.Batch(n) as b:
         assert np.array_equal(b.slot_map(), np.arange(n))            # before any positions: problem order
         b.set_problems(p0, p1, p2)
         slot = b.slot_map()
-        assert np.array_equal(np.sort(slot), np.arange(n))           # a permutation ...
-        assert np.array_equal(slot // 4096, np.arange(n) // 4096)    # ... within each window of 4,096 problems
+        assert np.array_equal(np.sort(slot), np.arange(n))           # a permutation
         prob_of = np.empty(n, dtype=np.int64)
         prob_of[slot] = np.arange(n)
-        q = np.floor(_ratio(p0, p1, p2)[prob_of] * 1048575.0)        # the kernel's 20-bit key
-        for w in range(0, n, 4096):
-            assert np.all(np.diff(q[w:w + 4096]) >= 0), w
+        assert np.array_equal(prob_of, np.argsort(_schedule_key(p0, p1, p2), kind="stable"))
         b.init_default()
         assert np.array_equal(b.slot_map(), np.arange(n))            # identical problems: problem order again
 
