@@ -576,11 +576,11 @@ def test_zero_end_velocity_specialisation_is_bit_identical_to_the_general_kernel
         assert np.array_equal(a.get_state(), b.get_state())
         a.step(3); b.step(3)                           # streaming kernel
         assert np.array_equal(a.get_state(), b.get_state())
-        a.solve(1e-8, 200, 0); b.solve(1e-8, 200, 0)   # tiled solve
+        a.solve(1e-8, 200, 0); b.solve(1e-8, 200, 0)   # fused gated solve (k_solve_chunks)
         assert np.array_equal(a.get_state(), b.get_state()) and np.array_equal(a.get_iters()[0], b.get_iters()[0])
         a.set_problems(p0, p1, p2); b.set_problems(p0, p1, p2)
         b.nudge(15, 2.0); b.nudge(15, -2.0)            # vel2X
-        a.solve(1e-8, 200, 3); b.solve(1e-8, 200, 3)   # plain gated kernel
+        a.solve(1e-8, 200, 3); b.solve(1e-8, 200, 3)   # the same kernel in rounds of 3 steps, host-polled
         assert np.array_equal(a.get_state(), b.get_state())
 
 
@@ -599,8 +599,9 @@ def test_non_zero_end_velocities_against_oracle(oracle, g3):
     assert np.array_equal(out[:, 11:], st[:, 11:])
 
 
-def test_non_zero_end_velocities_through_the_tiled_kernels_against_oracle(oracle):
-    # k_solve_tiled<..., ZV=false> (gated and ungated) had only ever seen zero end velocities.
+def test_non_zero_end_velocities_through_the_large_batch_kernels_against_oracle(oracle):
+    # the large-batch kernels' ZV=false instantiations (gated k_solve_chunks, ungated k_steps_tiled) had only
+    # ever seen zero end velocities.
     # 512 full tiles + a ragged tail; end velocities small enough that the start stays feasible (|da| <= 0.4 of the
     # 2.04 margin of the feasible-start rule).
     n = 512 * 512 + 301
@@ -614,7 +615,7 @@ def test_non_zero_end_velocities_through_the_tiled_kernels_against_oracle(oracle
     init[:, 15] = 0.1 * rng.uniform(-1, 1, n) * init[:, 2]
     with rp.Batch(n) as b:
         b.set_state(init)
-        b.solve(1e-8, 200, 0)                 # tiled gated solve, general instantiation
+        b.solve(1e-8, 200, 0)                 # fused gated solve, general instantiation
         it, status = b.get_iters()
         st = b.get_state()
         b.set_state(init)
