@@ -174,7 +174,7 @@ def main():
     lead = rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank)
     stream = lead.stream()
     # one batch per pass up to POOL of them (136 MB each at 1 Mi problems); longer runs cycle through the pool and
-    # pay the re-initialisation of a recycled batch inside the timed region (conservative: ~6 % of a pass)
+    # pay the restart of a recycled batch inside the timed region (conservative: ~10 % of a pass)
     POOL = 48
     n_batches = max(1, min(K + W, POOL))
     batches = [lead] + [rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) for _ in range(n_batches - 1)]
@@ -186,7 +186,7 @@ def main():
     def pass_(index):
         b = batches[index % n_batches]
         if index >= n_batches:
-            b.set_problems_device(*ptrs)
+            b.restart()      # back to the feasible start of the positions it already holds (device side only)
         b.solve(GAP_TOL, MAX_ITER, 0)
         return b
     summary = torch.zeros(4, dtype=torch.float64, device=torch.device("cuda", local_rank))

@@ -1,4 +1,6 @@
-"""Probe: how much a better schedule would buy.  The problems are pre-sorted on the HOST (what a different scheduled order
+"""HISTORICAL (kept for the logs profiles/r2_chunks_probe_*.log): ran against probe builds of the library that had the
+switches RP_NO_SCHEDULE / RP_PROBE_LINEAR; the shipped library schedules every batch itself (csrc/schedule.hip) and ignores them.
+Probe: how much a better schedule would buy.  The problems are pre-sorted on the HOST (what a different scheduled order
 inside the batch would give) and the library's own scheduling is switched off (RP_NO_SCHEDULE=1); RP_PROBE_LINEAR=1 makes the
 gated kernel walk the chunks from the last to the first.
 usage: chunks_probe.py none | ratio | ratio:B+len   (global sorts)"""
