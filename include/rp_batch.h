@@ -117,7 +117,10 @@ RP_API int rp_batch_info(const rp_batch *b, int *variant, int *dtype, int *devic
 RP_API int rp_batch_init_default(rp_batch *b); /* initDefault, onedpath_ip.cpp:201-228 / onedpath2_ip.cpp:164-193 */
 RP_API int rp_batch_init_stuck(rp_batch *b);   /* initStuck, onedpath_ip.cpp:177-199 (F3 only) */
 /* Per-problem positions (host arrays of n doubles), then the feasible start rule of
- * SURVEY.md 8d on the device: vel = 0, t_i = (3.5/sqrt 12) sqrt(6 |dX_i| / L), multipliers 1. */
+ * SURVEY.md 8d on the device: vel = 0, t_i = (3.5/sqrt 12) sqrt(6 |dX_i| / L), multipliers 1.
+ * This (and rp_batch_set_state) is also where the batch decides in which order it keeps its problems internally
+ * (sorted by expected step count, for the gated solve); callers never see that order except through
+ * rp_batch_field_ptr: problem i of every call below is the problem of element i of these arrays. */
 RP_API int rp_batch_set_problems(rp_batch *b, const double *pos0, const double *pos1, const double *pos2);
 /* Same with device-resident inputs (no PCIe in the path). */
 RP_API int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double *d_pos1, const double *d_pos2);
