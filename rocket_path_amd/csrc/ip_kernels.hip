@@ -1,7 +1,7 @@
 // ip_kernels.hip -- HIP kernels of the batched interior-point path, gfx950 only.
 //
-// Data layout in HBM: structure of arrays.  Field f of problem i lives at
-// base[f * stride + i]; the field order is the reference's enum order (enum V,
+// Data layout in HBM: structure of arrays.  Field f of the problem at position s lives at
+// base[f * stride + s]; the field order is the reference's enum order (enum V,
 // onedpath_ip.cpp:15-43; enum V2, onedpath2_ip.cpp:15-39), so field 0..2 are the variables,
 // 3..3+m-1 the multipliers and the last five the constants.  The stride is an odd multiple of 512
 // elements (rp_batch.cpp: a power-of-two distance between the fields puts all of them on one HBM
