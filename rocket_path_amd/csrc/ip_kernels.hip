@@ -187,6 +187,28 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
 // the blocks walk the order from its end, so the longest chunks start first.
 // Which lane solves which problem changes nothing in any problem's result (lanes never interact); a stale order
 // (positions nudged after it was computed) is merely a less effective schedule.
+#ifdef RP_TRACE      // tuning build (profiles/probes/chunk_trace.hip): per chunk (SIMD, start, end, steps) in 100 MHz ticks
+__device__ unsigned long long g_trace[4 * 32768];
+#define RP_TRACE_BEGIN() const unsigned long long trace_t0 = wall_clock64()
+#define RP_TRACE_END(c, steps)                                                                      \
+    do {                                                                                            \
+        const unsigned long long trace_t1 = wall_clock64();                                         \
+        int smax = (steps);                                                                         \
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(smax, o); smax = other > smax ? other : smax; } \
+        if (threadIdx.x == 0 && (c) < 32768u) {                                                     \
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       /* HW_REG_HW_ID: simd [5:4], cu [11:8], se [15:13] */ \
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;   /* HW_REG_XCC_ID */ \
+            g_trace[4 * (c) + 0] = ((unsigned long long)xcc << 32) | hw;                            \
+            g_trace[4 * (c) + 1] = trace_t0;                                                        \
+            g_trace[4 * (c) + 2] = trace_t1;                                                        \
+            g_trace[4 * (c) + 3] = (unsigned long long)smax;                                        \
+        }                                                                                           \
+    } while (0)
+#else
+#define RP_TRACE_BEGIN() do {} while (0)
+#define RP_TRACE_END(c, steps) do {} while (0)
+#endif
+
 // (mu_mode 1 carries the split direction: ~210 VGPRs, two waves per SIMD)
 template <typename S, typename T, int VARIANT, bool STALL, bool ZV, int MU = 0>
 __global__ void __launch_bounds__(64, MU == 1 ? RP_NEWTON_WAVES : RP_TILED_WAVES)
@@ -195,6 +217,7 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;   // first constant field: pos0, vel0, pos1, pos2, vel2
+    RP_TRACE_BEGIN();
     const unsigned chunk = gridDim.x - 1 - blockIdx.x;      // the scheduled order ends with the longest problems: they start first
     const size_t i = (size_t)chunk * 64 + threadIdx.x;
 
@@ -238,6 +261,7 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
         }
     }
 
+    RP_TRACE_END(blockIdx.x, steps_here);
     const unsigned long long open_mask = __ballot(still_open);
     const int steps_wave = wave_sum<int>(steps_here);
     if (threadIdx.x == 0) {
