@@ -462,20 +462,20 @@ def test_headless_shell_reproduces_the_survey_kats(golden_dir):
     assert "Node 1: pos=200" in out.stdout and "Duration 0:" in out.stdout
 
 
-# ---------------------------------------------------------------- the tiled fused solve (n >= 262,144)
-def test_tiled_solve_ragged_tail_and_resume(oracle):
-    # 512 full tiles + a 333-problem tail: the tiled kernel, its scheduling order and the ragged last tile
+# ---------------------------------------------------------------- the fused gated solve on large batches
+def test_fused_solve_ragged_tail_and_resume(oracle):
+    # 4,101 full 64-problem chunks of the scheduled order + a 13-problem tail
     n = 512 * 512 + 333
     p0, p1, p2 = rp.problems.generate(4242, 0, n, rp.problems.DIST_MONOTONE)
     with rp.Batch(n) as a, rp.Batch(n) as b:
         a.set_problems(p0, p1, p2)
         b.set_problems(p0, p1, p2)
-        a.solve(1e-8, 200, 0)            # fused: tiled, scheduled
-        b.solve(1e-8, 200, 7)            # plain kernel, 7 steps per launch
+        a.solve(1e-8, 200, 0)            # fused: one launch
+        b.solve(1e-8, 200, 7)            # the same kernel in host-polled rounds of 7 steps
         sa, sb = a.get_state(), b.get_state()
         ia, ta = a.get_iters()
         ib, tb = b.get_iters()
-        assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(ta, tb)   # schedule changes nothing
+        assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(ta, tb)   # the launch shape changes nothing
         assert a.reduce()["total_steps"] == float(ia.sum())
         # resume: a capped solve continued later equals the uninterrupted one
         b.set_problems(p0, p1, p2)
@@ -490,8 +490,9 @@ def test_tiled_solve_ragged_tail_and_resume(oracle):
         assert serr(sa[sl, :3][ok], aos[ok, :3]) < TOL
 
 
-def test_tiled_solve_survives_a_stale_order():
-    # nudging positions after the order was computed only makes the schedule less effective
+def test_fused_solve_survives_a_stale_order():
+    # nudging positions after the scheduled order was computed only makes the schedule less effective: same results as a
+    # batch that was scheduled on the nudged positions
     n = 512 * 512
     p0, p1, p2 = rp.problems.generate(99, 0, n, rp.problems.DIST_MONOTONE)
     with rp.Batch(n) as a, rp.Batch(n) as b:
@@ -505,7 +506,7 @@ def test_tiled_solve_survives_a_stale_order():
         assert np.array_equal(a.get_iters()[0], b.get_iters()[0])
 
 
-def test_tiled_solve_f4_fp32_matches_plain_kernel():
+def test_fused_solve_f4_fp32_matches_the_host_polled_rounds():
     n = 512 * 512 + 5
     p0, p1, p2 = rp.problems.generate(5, 0, n, rp.problems.DIST_MONOTONE)
     with rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32) as a, rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32) as b:
