@@ -2,9 +2,9 @@
 """Tiny workload for the SQ counter passes (rocprofv3 --pmc ... -- python3 profiles/pmc_probe.py).
 Every launch whose per-lane-step instruction counts are read from the counters is an ALL-LANES-ACTIVE launch of a
 known number of steps at 1 Mi problems:
-    F3 f64          12 fused ungated steps   -> k_steps_tiled<double, double, 3, true>
-    F4 f32          12 fused ungated steps   -> k_steps_tiled<float, float, 4, true>
-    F4 f32 state    12 fused ungated steps   -> k_steps_tiled<float, double, 4, true>
+    F3 f64          12 fused ungated steps   -> k_steps_chunks<double, double, 3, true>
+    F4 f32          12 fused ungated steps   -> k_steps_chunks<float, float, 4, true>
+    F4 f32 state    12 fused ungated steps   -> k_steps_chunks<float, double, 4, true>
 then the gated kernel (k_solve_chunks) on 524,288 identical default problems (15 steps each: its instructions per step without idle lanes),
 the benchmark's gated solve (occupancy / busy counters of the real launch) and one k = 1 launch."""
 import os

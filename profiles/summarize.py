@@ -75,13 +75,13 @@ alias("k_newton_stream16_f4_f32", "k_newton_stream16<float, float, 4, true", "10
 alias("k_newton_stream16_f4_f32state", "k_newton_stream16<float, double, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
 alias("k_steps_regrouped_f4_f32", "k_steps_regrouped<float, float, 4", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per 50-step launch")
 alias("k_steps_regrouped_f4_f32state", "k_steps_regrouped<float, double, 4", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per 50-step launch")
-alias("k_steps_tiled_f3_f64", "k_steps_tiled<double, double, 3, true", "14x8 B read + 11x8 B written per problem = 117.4 + 92.3 MB per launch")
+alias("k_steps_chunks_f3_f64", "k_steps_chunks<double, double, 3, true", "14x8 B read + 11x8 B written per problem = 117.4 + 92.3 MB per launch")
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag), "w"), indent=1)
 
 def real_grid(name):
-    """Work-items of the 1 Mi-problem launch of a Newton kernel of the probe: one lane per problem in the gated kernel, two
-    problems per lane (tile rounds / 16-byte accesses) in the others."""
-    return N if name.startswith("k_solve_chunks") else N // 2
+    """Work-items of the 1 Mi-problem launch of a Newton kernel of the probe: one lane per problem in the chunk kernels, two
+    problems per lane (16-byte accesses) in the streaming kernel."""
+    return N if name.startswith(("k_solve_chunks", "k_steps_chunks")) else N // 2
 
 
 sq = {}
@@ -103,7 +103,7 @@ for name, c in sq.items():
 lane_steps = float(PROBE_STEPS) * N
 top = {}
 for name, c in sq.items():
-    if not name.startswith("k_steps_tiled") or not name.endswith(", true>"):
+    if not name.startswith("k_steps_chunks") or not name.endswith(", true>"):
         continue
     f64 = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0)
                   + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) / lane_steps
@@ -112,11 +112,11 @@ for name, c in sq.items():
     c["flop_f64_per_lane_step"], c["flop_f32_per_lane_step"] = f64, f32
     if "SQ_INSTS_VALU" in c:
         c["valu_insts_per_lane_step"] = 64.0 * c["SQ_INSTS_VALU"] / lane_steps
-    if name.startswith("k_steps_tiled<double, double, 3"):
+    if name.startswith("k_steps_chunks<double, double, 3"):
         top["_flop_per_newton_step"] = f64
-    elif name.startswith("k_steps_tiled<float, float, 4"):
+    elif name.startswith("k_steps_chunks<float, float, 4"):
         top["_flop_per_f4_step_f32"] = f32 + f64
-    elif name.startswith("k_steps_tiled<float, double, 4"):
+    elif name.startswith("k_steps_chunks<float, double, 4"):
         top["_flop_per_f4_step_f32state"] = f64
 # the gated kernel on identical problems: 15 steps per problem, no idle lanes
 GATED = "k_solve_chunks<double, double, 3, false, true, 0>"

@@ -17,8 +17,7 @@
 //   k_solve_chunks     the gated solve (the benchmark's kernel): one 64-problem chunk of the scheduled order per
 //                      single-wave block, state in registers from its first load to its last store, no LDS, longest
 //                      chunks dispatched first
-//   k_steps_tiled      k >= 3 ungated steps on large batches: one 512-problem tile per 256-thread block, staged in LDS
-//                      (this is the form whose registers fit three waves per SIMD)
+//   k_steps_chunks     k >= 3 ungated steps on large batches: the same shape, fixed step count
 //   k_newton_stream16  k <= 2 ungated steps, the HBM-streaming form: 16 B per lane (two doubles / four floats =
 //                      that many consecutive problems per lane), one global_load/store_dwordx4 per field
 //   k_newton_stream    the same with one problem per lane and a register prefetch: ragged remainders, small
@@ -87,7 +86,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 #define RP_NEWTON_WAVES 2     // minimum waves per SIMD the register allocator must leave room for
 #endif
 #ifndef RP_TILED_WAVES
-#define RP_TILED_WAVES 3     // the tiled kernels fit 168 VGPRs (gated: 130) and 48 KiB of LDS per block: three blocks per CU
+#define RP_TILED_WAVES 3     // the large-batch kernels fit 168 VGPRs (gated solve: 136, fixed steps: 152; F4 regrouping: + 48 KiB of LDS per block)
 #endif
 
 // The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
@@ -250,14 +249,18 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
             pr.dx1 = p2 - p1;
         }
         run_lane<T, VARIANT, true, STALL, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
-        iters[i] = it;
-        status[i] = st;
+        // the store addresses are formed only now (the barrier keeps the compiler from holding them in registers across the steps)
+        size_t j = (size_t)chunk * 64 + threadIdx.x;
+        asm volatile("" : "+v"(j));
+        iters[j] = it;
+        status[j] = st;
         if (steps_here > 0) {
-            st_once(f + 0 * stride, (S)v);
-            st_once(f + 1 * stride, (S)t0);
-            st_once(f + 2 * stride, (S)t1);
+            S *g = base + j;
+            st_once(g + 0 * stride, (S)v);
+            st_once(g + 1 * stride, (S)t0);
+            st_once(g + 2 * stride, (S)t1);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) st_once(f + (3 + c) * stride, (S)lam[c]);
+            for (int c = 0; c < NC; ++c) st_once(g + (3 + c) * stride, (S)lam[c]);
         }
     }
 
@@ -269,6 +272,53 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
         if (open_mask) atomicAdd(&counters[shard], (unsigned long long)__popcll(open_mask));
         if (steps_wave) atomicAdd(&counters[kShards + shard], (unsigned long long)steps_wave);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// k >= 3 ungated steps per problem on large batches: arithmetic-bound like the gated solve, and the same shape -- one
+// single-wave block per 64 consecutive positions, state loaded straight into registers, k steps, stored; no LDS.  (Until
+// late in round 2 this was a 512-problem tile staged in LDS, the only form that fitted three waves per SIMD: the compiler
+// kept the eleven store addresses in registers across the steps.  Forming them after the steps, below, saved 16 VGPRs and
+// made the direct form both fit and win: 57.5 -> 65.5 G steps/s at k = 12.)
+template <typename S, typename T, int VARIANT, bool ZV>
+__global__ void __launch_bounds__(64, RP_TILED_WAVES)
+k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    constexpr int CB = 3 + NC;
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    S *f = base + i;
+    T v = (T)ld_once(f + 0 * stride), t0 = (T)ld_once(f + 1 * stride), t1 = (T)ld_once(f + 2 * stride);
+    T lam[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) lam[c] = (T)ld_once(f + (3 + c) * stride);
+    Prob<T, ZV> pr;
+    {
+        const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
+        if constexpr (!ZV) {
+            pr.v0 = (T)f[(CB + 1) * stride];
+            pr.v2 = (T)f[(CB + 4) * stride];
+        }
+        pr.dx0 = p1 - p0;
+        pr.dx1 = p2 - p1;
+    }
+    int it = 0, steps_here = 0;
+    uint32_t st = 0u;
+    bool still_open = false;
+    // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
+    // its stalled problems), so all its fixed-step kernels use it and agree bit for bit; F3's would spill at three waves
+    run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+    // the store addresses are formed only now: the barrier keeps the compiler from holding eleven of them in registers
+    // across the steps (168 VGPRs and 4-10 spilled without it, 152 with it)
+    size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
+    asm volatile("" : "+v"(j));
+    S *g = base + j;
+    st_once(g + 0 * stride, (S)v);
+    st_once(g + 1 * stride, (S)t0);
+    st_once(g + 2 * stride, (S)t1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) st_once(g + (3 + c) * stride, (S)lam[c]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -453,77 +503,14 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
 }
 
 // ---------------------------------------------------------------------------------------
-// k ungated steps per problem on large batches, tiled.  For k >= 3 the arithmetic dominates; the fixed-step body needs
-// ~165 VGPRs, and a kernel that loads its 16 fields straight into registers while the previous values are still live does
-// not fit three waves per SIMD.  Here each 256-thread block stages one tile of 512 consecutive problems in LDS (the 11
-// MUTABLE fields, 44 KiB in f64, coalesced both ways; the five constants are read once per problem) and every lane
-// steps two of them one after the other out of LDS: 168 VGPRs, no scratch, three blocks per CU.
+// Tiles of the F4 regrouping kernel below: 512 consecutive positions per 256-thread block, staged in LDS.
 #ifndef RP_TILE
-#define RP_TILE 512      // problems per tile of the tiled kernels; their blocks have RP_TILE / 2 threads (each wave two 64-problem chunks)
+#define RP_TILE 512      // problems per tile; the block has RP_TILE / 2 threads (each wave two 64-problem chunks)
 #endif
 constexpr int kTile = RP_TILE;
 constexpr int kTileThreads = kTile / 2;
-constexpr size_t kTiledMin = 262144;      // below this many problems the tiled kernels cannot fill the chip
+constexpr size_t kTiledMin = 262144;      // below this many problems the large-batch fixed-step kernels cannot fill the chip
 constexpr int kBuckets = 64;
-
-// Every instantiation fits 168 VGPRs without scratch (profiles/kernel_resources.py; any scratch makes the launch time erratic).
-template <typename S, typename T, int VARIANT, bool ZV>
-__global__ void __launch_bounds__(kTileThreads, RP_TILED_WAVES)
-k_steps_tiled(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
-{
-    constexpr int NC = CMap<VARIANT>::NC;
-    constexpr int CB = 3 + NC;
-    __shared__ S sm[CB][kTile];            // the mutable fields only; the five constants are read once per problem
-
-    const int tid = threadIdx.x;
-    const size_t first = (size_t)blockIdx.x * kTile;
-    const int count = (n - first < (size_t)kTile) ? (int)(n - first) : kTile;
-
-    // -- stage the tile: field-major in LDS, every global access a full coalesced segment
-#pragma unroll
-    for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kTileThreads) sm[f][j] = ld_once(base + (size_t)f * stride + first + j);
-    __syncthreads();
-
-#pragma unroll 1
-    for (int round = 0; round < 2; ++round) {
-        const int j = round * kTileThreads + tid;
-        if (j < count) {
-            T v = (T)sm[0][j], t0 = (T)sm[1][j], t1 = (T)sm[2][j];
-            T lam[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) lam[c] = (T)sm[3 + c][j];
-            Prob<T, ZV> pr;
-            {
-                const S *g = base + first + j;
-                const T q0 = (T)g[(size_t)(CB + 0) * stride], q1 = (T)g[(size_t)(CB + 2) * stride], q2 = (T)g[(size_t)(CB + 3) * stride];
-                if constexpr (!ZV) {
-                    pr.v0 = (T)g[(size_t)(CB + 1) * stride];
-                    pr.v2 = (T)g[(size_t)(CB + 4) * stride];
-                }
-                pr.dx0 = q1 - q0;
-                pr.dx1 = q2 - q1;
-            }
-            int it = 0, steps_here = 0;
-            uint32_t st = 0u;
-            bool still_open = false;
-            // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
-            // its stalled problems), so all its fixed-step kernels use it and agree bit for bit; F3's tiled kernel would spill
-            run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
-            sm[0][j] = (S)v;
-            sm[1][j] = (S)t0;
-            sm[2][j] = (S)t1;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) sm[3 + c][j] = (S)lam[c];
-        }
-    }
-    __syncthreads();
-
-    // -- write the tile back
-#pragma unroll
-    for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kTileThreads) st_once(base + (size_t)f * stride + first + j, sm[f][j]);
-}
 
 // ---------------------------------------------------------------------------------------
 // Fixed-step runs of F4: k ungated steps per problem with the tile's problems REGROUPED every few steps by what their line
@@ -1026,7 +1013,7 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     // k <= 2 is memory-bound: the streaming kernel, grid = the resident set (256 CUs x 2 blocks) so that each lane
     // walks 8 problems at 1 Mi and its register prefetch hides the HBM latency.  Larger k is arithmetic-bound: there
     // the second register set of the prefetch only costs occupancy, so k >= 3 on a batch large enough to fill the
-    // chip with 512-problem tiles runs the tiled kernel, ungated (168 VGPRs with zero end velocities: 3 waves per SIMD).
+    // chip runs k_steps_chunks (one problem per lane, no prefetch, 152 VGPRs: 3 waves per SIMD).
     static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override: forces the streaming kernel
     if (k >= 3 && !grid_env && b.n >= kTiledMin) {
         const unsigned tiles = (unsigned)((b.n + kTile - 1) / kTile);
@@ -1037,7 +1024,7 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
                                                                       (S *)b.base, b.stride, b.n, k, every, make_kparams<T>(hp, 4)));
             return hipGetLastError();
         }
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_tiled<S, T, V, Z>), dim3(tiles), dim3(kTileThreads), 0, stream,
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V, Z>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
                                              (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
         return hipGetLastError();
     }

@@ -134,7 +134,7 @@ def test_field_ptr_to_an_end_velocity_selects_the_general_kernels(oracle):
     paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}, key=lambda p: "torch" in p)
     hip_path = paths[0]
     hip = ctypes.CDLL(hip_path)
-    n = 512 * 512 + 9                           # large enough for the tiled kernels
+    n = 512 * 512 + 9                           # large enough for the large-batch kernels
     p0, p1, p2 = rp.problems.generate(77, 0, n, rp.problems.DIST_MONOTONE)
     v0 = np.linspace(-0.05, 0.05, n)
     v2 = np.linspace(0.04, -0.04, n)

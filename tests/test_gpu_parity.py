@@ -601,7 +601,7 @@ def test_non_zero_end_velocities_against_oracle(oracle, g3):
 
 
 def test_non_zero_end_velocities_through_the_large_batch_kernels_against_oracle(oracle):
-    # the large-batch kernels' ZV=false instantiations (gated k_solve_chunks, ungated k_steps_tiled) had only
+    # the large-batch kernels' ZV=false instantiations (gated k_solve_chunks, ungated k_steps_chunks) had only
     # ever seen zero end velocities.
     # 512 full tiles + a ragged tail; end velocities small enough that the start stays feasible (|da| <= 0.4 of the
     # 2.04 margin of the feasible-start rule).
@@ -620,7 +620,7 @@ def test_non_zero_end_velocities_through_the_large_batch_kernels_against_oracle(
         it, status = b.get_iters()
         st = b.get_state()
         b.set_state(init)
-        b.step(5)                             # tiled ungated steps, general instantiation
+        b.step(5)                             # large-batch fixed steps (k_steps_chunks), general instantiation
         st5 = b.get_state()
     assert np.all(status == rp.ST_CONVERGED)
     assert np.array_equal(st[:, 11:], init[:, 11:])
@@ -641,8 +641,8 @@ def test_non_zero_end_velocities_through_the_large_batch_kernels_against_oracle(
     assert serr(st5[sl_list[0], :3], zero[:, :3]) > 1e-6
 
 
-def test_tiled_ungated_steps_equal_streamed_single_steps_bitwise():
-    # k >= 3 on a large batch runs the tiled kernel (ungated), k = 1 the streaming kernel: same arithmetic, same bits
+def test_large_batch_fixed_steps_equal_streamed_single_steps_bitwise():
+    # k >= 3 on a large batch runs k_steps_chunks, k = 1 the streaming kernel: same arithmetic, same bits
     n = 512 * 512 + 77
     p0, p1, p2 = rp.problems.generate(2025, 0, n, rp.problems.DIST_MONOTONE)
     with rp.Batch(n) as a, rp.Batch(n) as b:
@@ -819,7 +819,7 @@ def test_f4_regrouped_fixed_steps_equal_single_steps_bitwise(dtype):
     with rp.Batch(n, rp.VARIANT_F4, dtype) as a, rp.Batch(n, rp.VARIANT_F4, dtype) as b:
         a.set_problems(p0, p1, p2)
         b.set_problems(p0, p1, p2)
-        a.step(14)                       # tiled kernel (k < 20)
+        a.step(14)                       # k_steps_chunks (k < 20)
         for _ in range(14):
             b.step(1)                    # streaming kernel
         sa, sb = a.get_state(), b.get_state()

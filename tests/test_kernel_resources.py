@@ -30,21 +30,21 @@ def test_headline_kernels_fit_three_waves_without_scratch():
         m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", line)
         if m and name:
             usage[name][m.group(1)] = int(m.group(2))
-    # the benchmark's kernel k_solve_chunks<double, double, 3, STALL=false, ZV=true, MU=0> and the ungated tiled kernel
-    # k_steps_tiled<double, double, 3, ZV=true>
+    # the benchmark's kernel k_solve_chunks<double, double, 3, STALL=false, ZV=true, MU=0> and its fixed-step sibling
+    # k_steps_chunks<double, double, 3, ZV=true>
     gated = {k: v for k, v in usage.items() if "k_solve_chunksIddLi3ELb0ELb1ELi0E" in k}
-    tiled = {k: v for k, v in usage.items() if "k_steps_tiledIddLi3ELb1E" in k}
-    assert len(gated) == 1 and len(tiled) == 1, sorted(usage)
-    for k, v in list(gated.items()) + list(tiled.items()):
+    fixed = {k: v for k, v in usage.items() if "k_steps_chunksIddLi3ELb1E" in k}
+    assert len(gated) == 1 and len(fixed) == 1, sorted(usage)
+    for k, v in list(gated.items()) + list(fixed.items()):
         assert v["VGPRs"] <= 168, (k, v)
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (k, v)
         assert 3 * v["LDS Size [bytes/block]"] <= 160 * 1024, (k, v)
-    for k, v in gated.items():
+    for k, v in list(gated.items()) + list(fixed.items()):
         assert v["LDS Size [bytes/block]"] == 0, (k, v)      # state goes from HBM to registers and back, nothing staged
     # nothing on the Newton path may spill in its default build
     checked = 0
     for k, v in usage.items():
-        if "k_newton" in k or "k_solve_chunks" in k or "k_steps_tiled" in k or "k_steps_regrouped" in k:
+        if "k_newton" in k or "k_solve_chunks" in k or "k_steps_chunks" in k or "k_steps_regrouped" in k:
             assert v.get("VGPRs Spill", 0) == 0, (k, v)
             checked += 1
     assert checked > 60
