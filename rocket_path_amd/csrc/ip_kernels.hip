@@ -17,11 +17,10 @@
 //   k_solve_chunks     the gated solve (the benchmark's kernel): one 64-problem chunk of the scheduled order per
 //                      single-wave block, state in registers from its first load to its last store, no LDS, longest
 //                      chunks dispatched first
-//   k_steps_chunks     k >= 3 ungated steps on large batches: the same shape, fixed step count
+//   k_steps_chunks     k >= 3 ungated steps: the same shape, fixed step count
 //   k_newton_stream16  k <= 2 ungated steps, the HBM-streaming form: 16 B per lane (two doubles / four floats =
 //                      that many consecutive problems per lane), one global_load/store_dwordx4 per field
-//   k_newton_stream    the same with one problem per lane and a register prefetch: ragged remainders, small
-//                      batches with k >= 3 (more waves than the 16-byte form), mu_mode 1
+//   k_newton_stream    the same with one problem per lane and a register prefetch: ragged remainders, mu_mode 1
 //   k_steps_regrouped  F4's long fixed-step runs (k >= 20) on large batches: tiles re-sorted by line-search cost every 4 steps
 // Problems are independent and nothing is re-read, so there is no L2 locality to arrange: consecutive blocks are dealt
 // round-robin over the 8 XCDs and touch disjoint cache lines.
@@ -509,7 +508,7 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
 #endif
 constexpr int kTile = RP_TILE;
 constexpr int kTileThreads = kTile / 2;
-constexpr size_t kTiledMin = 262144;      // below this many problems the large-batch fixed-step kernels cannot fill the chip
+constexpr size_t kTiledMin = 262144;      // below this many problems the 512-problem tiles of k_steps_regrouped cannot fill the chip
 constexpr int kBuckets = 64;
 
 // ---------------------------------------------------------------------------------------
@@ -1012,14 +1011,15 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     // resident set: 256 CUs x 2 blocks (2 waves per SIMD); larger batches are walked with that stride
     // k <= 2 is memory-bound: the streaming kernel, grid = the resident set (256 CUs x 2 blocks) so that each lane
     // walks 8 problems at 1 Mi and its register prefetch hides the HBM latency.  Larger k is arithmetic-bound: there
-    // the second register set of the prefetch only costs occupancy, so k >= 3 on a batch large enough to fill the
-    // chip runs k_steps_chunks (one problem per lane, no prefetch, 152 VGPRs: 3 waves per SIMD).
+    // the second register set of the prefetch only costs occupancy, so k >= 3 runs k_steps_chunks (one problem per lane,
+    // no prefetch, 152 VGPRs: 3 waves per SIMD) at every batch size -- measured equal or faster than the prefetching
+    // kernel down to 4,096 problems, 65,536 x 50 steps included (0.333 against 0.363 ms).
     static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override: forces the streaming kernel
-    if (k >= 3 && !grid_env && b.n >= kTiledMin) {
+    if (k >= 3 && !grid_env) {
         const unsigned tiles = (unsigned)((b.n + kTile - 1) / kTile);
         static const bool no_regroup = getenv("RP_NO_REGROUP") != nullptr;      // A/B switch for tuning
         static const int every = getenv("RP_REGROUP_EVERY") ? atoi(getenv("RP_REGROUP_EVERY")) : 4;      // tuning
-        if (b.variant == 4 && k >= 20 && !no_regroup && every >= 1) {      // F4's long fixed-step runs: see k_steps_regrouped
+        if (b.variant == 4 && k >= 20 && b.n >= kTiledMin && !no_regroup && every >= 1) {      // F4's long fixed-step runs on large batches: see k_steps_regrouped
             RP_DISPATCH_Z(b, if constexpr (V == 4) hipLaunchKernelGGL((k_steps_regrouped<S, T, 4, Z>), dim3(tiles), dim3(kTileThreads), 0, stream,
                                                                       (S *)b.base, b.stride, b.n, k, every, make_kparams<T>(hp, 4)));
             return hipGetLastError();
@@ -1032,7 +1032,7 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     // under RP_STREAM_SCALAR=1, everything: the A/B switch of the tuning log) through the 8-byte prefetching kernel.
     static const bool scalar_only = getenv("RP_STREAM_SCALAR") != nullptr;
     const size_t per_block = (size_t)kBlock * (b.dtype == 1 ? 4 : 2);      // problems per lane: Vec16<S, T>::PER
-    const size_t nfull = (scalar_only || grid_env || k > 2) ? 0 : b.n / per_block * per_block;      // k >= 3 on a small batch: one problem per lane fills more SIMDs
+    const size_t nfull = (scalar_only || grid_env || k > 2) ? 0 : b.n / per_block * per_block;      // (k > 2 only under RP_STREAM_GRID)
     if (nfull > 0)
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_newton_stream16<S, T, V, Z>), dim3((unsigned)(nfull / per_block)), dim3(kBlock), 0, stream,
                                              (S *)b.base, b.stride, k, make_kparams<T>(hp, V)));
