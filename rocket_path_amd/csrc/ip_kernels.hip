@@ -470,6 +470,13 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
 #else
         if (!(ZV && (q == CB + 1 || q == CB + 4))) f[q] = *reinterpret_cast<const V *>(base + (size_t)q * stride + i);
 #endif
+    // the segment lengths of all PER problems up front: the three position vectors are dead from here on
+    T dx0[PER], dx1[PER];
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+        dx0[c] = (T)f[CB + 2][c] - (T)f[CB + 0][c];
+        dx1[c] = (T)f[CB + 3][c] - (T)f[CB + 2][c];
+    }
 #pragma unroll
     for (int c = 0; c < PER; ++c) {
         T v = (T)f[0][c], t0 = (T)f[1][c], t1 = (T)f[2][c];
@@ -481,8 +488,8 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
             pr.v0 = (T)f[CB + 1][c];
             pr.v2 = (T)f[CB + 4][c];
         }
-        pr.dx0 = (T)f[CB + 2][c] - (T)f[CB + 0][c];
-        pr.dx1 = (T)f[CB + 3][c] - (T)f[CB + 2][c];
+        pr.dx0 = dx0[c];
+        pr.dx1 = dx1[c];
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
@@ -493,11 +500,13 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
 #pragma unroll
         for (int q = 0; q < NC; ++q) f[3 + q][c] = (S)lam[q];
     }
+    size_t j = ((size_t)blockIdx.x * kBlock + threadIdx.x) * PER;      // store addresses formed only now (see k_steps_chunks)
+    asm volatile("" : "+v"(j));
 #pragma unroll
 #ifndef RP_STREAM_PLAIN
-    for (int q = 0; q < CB; ++q) __builtin_nontemporal_store(f[q], reinterpret_cast<V *>(base + (size_t)q * stride + i));
+    for (int q = 0; q < CB; ++q) __builtin_nontemporal_store(f[q], reinterpret_cast<V *>(base + (size_t)q * stride + j));
 #else
-    for (int q = 0; q < CB; ++q) *reinterpret_cast<V *>(base + (size_t)q * stride + i) = f[q];
+    for (int q = 0; q < CB; ++q) *reinterpret_cast<V *>(base + (size_t)q * stride + j) = f[q];
 #endif
 }
 
