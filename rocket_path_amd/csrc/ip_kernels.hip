@@ -84,6 +84,9 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 #ifndef RP_NEWTON_WAVES
 #define RP_NEWTON_WAVES 2     // minimum waves per SIMD the register allocator must leave room for
 #endif
+#ifndef RP_GATED_WAVES
+#define RP_GATED_WAVES 3     // tuning knob: 4 (128 VGPRs, 6 spilled) and 2 were measured, DESIGN.md tuning log
+#endif
 #ifndef RP_TILED_WAVES
 #define RP_TILED_WAVES 3     // the large-batch kernels fit 168 VGPRs (gated solve: 136, fixed steps: 152; F4 regrouping: + 48 KiB of LDS per block)
 #endif
@@ -209,7 +212,7 @@ __device__ unsigned long long g_trace[4 * 32768];
 
 // (mu_mode 1 carries the split direction: ~210 VGPRs, two waves per SIMD)
 template <typename S, typename T, int VARIANT, bool STALL, bool ZV, int MU = 0>
-__global__ void __launch_bounds__(64, MU == 1 ? RP_NEWTON_WAVES : RP_TILED_WAVES)
+__global__ void __launch_bounds__(64, MU == 1 ? RP_NEWTON_WAVES : RP_GATED_WAVES)
 k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
                int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters)
 {
