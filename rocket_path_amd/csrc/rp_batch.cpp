@@ -31,6 +31,7 @@ struct rp_batch {
     uint32_t *d_words;        // lazily allocated 2 n words: per-problem words gathered from batch order into problem order
     void *d_sched;            // lazily allocated scratch of the scheduling sort (schedule.hip), sched_bytes bytes
     size_t sched_bytes;
+    hipEvent_t sched_ready, sched_done;      // order the sort (helper queue) against this batch's stream; created with d_sched
     double ungated_steps;     // per-problem count of ungated steps since the last init
     unsigned long long *h_pinned;   // 72 pinned host words: [0,64) counter shards, [64,68) reduction: read-backs without pageable staging
     hipEvent_t events[8];
@@ -94,7 +95,6 @@ int reset_progress(rp_batch *b)
 struct SchedQueue {
     std::mutex lock;
     hipStream_t stream = nullptr;
-    hipEvent_t ready = nullptr, done = nullptr;
 };
 constexpr int kMaxDevices = 64;
 SchedQueue g_sched[kMaxDevices];
@@ -105,6 +105,8 @@ int schedule(rp_batch *b, const double *d_pos0, const double *d_pos1, const doub
     if (!b->d_sched) {
         RP_HIP(rp::schedule_scratch_bytes(b->view.n, &b->sched_bytes));
         RP_HIP(hipMalloc(&b->d_sched, b->sched_bytes));
+        RP_HIP(hipEventCreateWithFlags(&b->sched_ready, hipEventDisableTiming));
+        RP_HIP(hipEventCreateWithFlags(&b->sched_done, hipEventDisableTiming));
     }
     // The sort runs on a queue of its own, ordered against the batch's stream by two events.  Measured
     // (profiles/probes/fixed50_order_probe.py): after rocPRIM's sort kernels have run on a queue, a later kernel on THAT
@@ -112,16 +114,12 @@ int schedule(rp_batch *b, const double *d_pos0, const double *d_pos1, const doub
     // has passed; other queues are unaffected.  One helper stream per device, shared by its batches (setup work only).
     SchedQueue &q = g_sched[b->device % kMaxDevices];
     std::lock_guard<std::mutex> hold(q.lock);
-    if (!q.stream) {
-        RP_HIP(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
-        RP_HIP(hipEventCreateWithFlags(&q.ready, hipEventDisableTiming));
-        RP_HIP(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
-    }
-    RP_HIP(hipEventRecord(q.ready, b->stream));          // the positions are where the caller's stream order says they are
-    RP_HIP(hipStreamWaitEvent(q.stream, q.ready, 0));
+    if (!q.stream) RP_HIP(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+    RP_HIP(hipEventRecord(b->sched_ready, b->stream));          // the positions are where the caller's stream order says they are
+    RP_HIP(hipStreamWaitEvent(q.stream, b->sched_ready, 0));
     RP_HIP(rp::launch_schedule(b->view, d_pos0, d_pos1, d_pos2, pstride, b->d_sched, b->sched_bytes, q.stream));
-    RP_HIP(hipEventRecord(q.done, q.stream));
-    RP_HIP(hipStreamWaitEvent(b->stream, q.done, 0));
+    RP_HIP(hipEventRecord(b->sched_done, q.stream));
+    RP_HIP(hipStreamWaitEvent(b->stream, b->sched_done, 0));
     b->view.scheduled = true;
     return RP_OK;
 }
@@ -267,6 +265,8 @@ int rp_batch_destroy(rp_batch *b)
     if (b->view.prob_of) (void)hipFree(b->view.prob_of);
     if (b->d_words) (void)hipFree(b->d_words);
     if (b->d_sched) (void)hipFree(b->d_sched);
+    if (b->sched_ready) (void)hipEventDestroy(b->sched_ready);
+    if (b->sched_done) (void)hipEventDestroy(b->sched_done);
     if (b->view.counters) (void)hipFree(b->view.counters);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);

@@ -367,3 +367,37 @@ def test_set_state_round_trips_in_problem_order(variant, dtype):
         assert not np.array_equal(b.slot_map(), np.arange(n))        # scheduled by the positions in the rows
         assert np.array_equal(b.get_state(), aos)
         assert np.array_equal(b.get_state_range(4000, 200), aos[4000:4200])
+
+
+def test_scheduling_on_the_helper_queue_stays_ordered_under_back_to_back_reuse(oracle):
+    # set_problems sorts on a helper queue, ordered against the batch's stream by two events.  Many batches on ONE stream,
+    # re-initialised (from device-resident positions: no host synchronisation anywhere) and solved back to back,
+    # alternating between three problem sets: a lost dependency would let the feasible start read a half-written order, or
+    # a solve start on a state that is still being rewritten, and the totals below would be off.
+    n = 4096 * 5 + 123
+    holders, ptrs, totals = [], [], []
+    for seed in (11, 22, 33):
+        p = rp.problems.generate(seed, 0, n, rp.problems.DIST_MONOTONE)
+        init = oracle.batch_init_feasible(3, *p)
+        it, _ = oracle.batch_solve_gated(3, init, 1e-8, 200)
+        totals.append(int(np.sum(it)))
+        h = rp.Batch(n)                  # keeps the positions in device memory (in ITS order: a permutation of the set,
+        h.set_problems(*p)               # i.e. the same problems and the same total)
+        holders.append(h)
+        ptrs.append([h.field_ptr(f) for f in (11, 13, 14)])      # pos0X, pos1X, pos2X of enum V
+    lead = rp.Batch(n)
+    batches = [lead] + [rp.Batch(n, stream=lead.stream()) for _ in range(7)]
+    try:
+        for rnd in range(12):
+            picks = [(rnd + j) % 3 for j in range(len(batches))]
+            for b, k in zip(batches, picks):
+                b.set_problems_device(*ptrs[k])
+                b.solve(1e-8, 200, 0)
+            for b, k in zip(batches, picks):
+                r = b.reduce()
+                assert r["n_converged"] == n
+                assert abs(r["total_steps"] - totals[k]) <= 3          # certified gate ties apart (a few per million)
+    finally:
+        for b in batches[1:] + holders:
+            b.close()
+        lead.close()
