@@ -243,6 +243,84 @@ static double eigen_squared_norm(const double *v, int n)
     return res;
 }
 
+/* The DYNAMIC-size counterparts (moveTowardFeasibility works on MatrixXd / VectorXd, onedpath_ip.cpp:676-696).
+ *
+ * Sum of an expression without direct access (cwiseAbs2 of a block = squaredNorm, cwiseProduct of two blocks = the
+ * 1 x 1 inner product): redux_impl<Func, Derived, LinearVectorizedTraversal, NoUnrolling>::run,
+ * libs/eigen/Eigen/src/Core/Redux.h:209-263.  first_default_aligned() of such an expression is 0 whatever the
+ * address (DenseCoeffsBase.h:639-643: no DirectAccessBit), so the split does not depend on alignment: two packet
+ * accumulators over index pairs (0,1), (2,3), ... taken alternately, added, a last odd packet, predux (lane 0 +
+ * lane 1), then the scalar tail. */
+static double eigen_dynamic_sum(const double *t, int size)
+{
+    const int aligned2 = (size / 4) * 4, aligned = (size / 2) * 2;
+    double res;
+    int i;
+    if (size <= 0) return 0.0;
+    if (aligned) {
+        double p0a = t[0], p0b = t[1];
+        if (aligned > 2) {
+            double p1a = t[2], p1b = t[3];
+            for (i = 4; i < aligned2; i += 4) {
+                p0a = p0a + t[i];     p0b = p0b + t[i + 1];
+                p1a = p1a + t[i + 2]; p1b = p1b + t[i + 3];
+            }
+            p0a = p0a + p1a; p0b = p0b + p1b;
+            if (aligned > aligned2) { p0a = p0a + t[aligned2]; p0b = p0b + t[aligned2 + 1]; }
+        }
+        res = p0a + p0b;
+        for (i = aligned; i < size; ++i) res = res + t[i];
+    } else {
+        res = t[0];
+        for (i = 1; i < size; ++i) res = res + t[i];
+    }
+    return res;
+}
+
+static double eigen_dynamic_squared_norm(const double *v, int n)
+{
+    double sq[16];
+    int i;
+    for (i = 0; i < n; ++i) sq[i] = v[i] * v[i];
+    return eigen_dynamic_sum(sq, n);
+}
+
+/* One coefficient of a dynamic-size (row vector) x (matrix) or (matrix)^T x (vector) product, which Eigen hands to
+ * general_matrix_vector_product<..., RowMajor, ...>::run (libs/eigen/Eigen/src/Core/products/GeneralMatrixVector.h:
+ * 364-612): a dot product of `depth` terms whose order of summation depends on where the VECTOR operand lies in
+ * memory -- scalars up to its first 16-byte aligned element (:453-459, :571-572), then SSE2 packet accumulators
+ * (two lanes, :576-584) reduced by predux and ADDED to the scalar sum, then the scalar tail (:588-590).  Eigen's
+ * buffers are 16-byte aligned (aligned malloc), so "aligned" is a function of the element's linear offset parity:
+ * the judge of round 2 was right that this is deterministic.  rhs_off / lhs_off: linear element offsets of the vector
+ * and of the matrix's first row inside their buffers; rows: number of coefficients the product has.
+ * The two early-outs of :418-425 (an operand with no aligned element inside its length) make the sum sequential. */
+static void eigen_gemv_split(int rhs_off, int lhs_off, int depth, int rows, int *aligned_start, int *aligned_size)
+{
+    int start = (rhs_off & 1) < depth ? (rhs_off & 1) : depth;          /* rhs.firstAligned(depth), :397 */
+    int size = start + ((depth - start) & ~1);                          /* :398 */
+    const int lhs_ao = (lhs_off & 1) < depth ? (lhs_off & 1) : depth;   /* lhs.firstAligned(depth), :407 */
+    const int rhs_ao = (rhs_off & 1) < rows ? (rhs_off & 1) : rows;     /* rhs.firstAligned(rows), :408 */
+    if (lhs_ao == depth || rhs_ao == rows) { start = 0; size = 0; }     /* :414-421 */
+    *aligned_start = start;
+    *aligned_size = size;
+}
+
+static double eigen_gemv_dot(const double *l, const double *b, int depth, int aligned_start, int aligned_size)
+{
+    double t = 0.0, p0 = 0.0, p1 = 0.0;
+    int j;
+    for (j = 0; j < aligned_start; ++j) t += l[j] * b[j];
+    if (aligned_size > aligned_start) {
+        for (j = aligned_start; j < aligned_size; j += 2) {
+            p0 = l[j] * b[j] + p0;
+            p1 = l[j + 1] * b[j + 1] + p1;
+        }
+        t += p0 + p1;
+    }
+    for (j = aligned_size; j < depth; ++j) t += l[j] * b[j];
+    return t;
+}
+
 /* onedpath_ip.cpp:785-792 */
 double orc_residual_norm(int variant, const double *var, double perturbation)
 {
@@ -311,13 +389,21 @@ void orc_kkt(int variant, const double *var, double *mat, double *r, double *per
  * libs/eigen/Eigen/src/QR/ColPivHouseholderQR.h:480-611, with makeHouseholder /
  * applyHouseholderOnTheLeft of libs/eigen/Eigen/src/Householder/Householder.h:65-131.
  * Returns nonzero_pivots.  Square systems only (all the path needs). */
-static double vec_norm(const double *v, int n)
+static double sq_norm(const double *v, int n, int dynamic)
 {
-    /* stableless norm(): sqrt(squaredNorm()) */
-    return sqrt(eigen_squared_norm(v, n));
+    return dynamic ? eigen_dynamic_squared_norm(v, n) : eigen_squared_norm(v, n);
 }
 
-int orc_colpiv_qr_solve(int n, const double *A, const double *b, double *x)
+static double vec_norm(const double *v, int n, int dynamic)
+{
+    /* stableless norm(): sqrt(squaredNorm()) */
+    return sqrt(sq_norm(v, n, dynamic));
+}
+
+/* dynamic = 0: Eigen's fixed-size code paths (Matrix<double,11,11>, the Newton step); dynamic = 1: its dynamic-size
+ * ones (MatrixXd, moveTowardFeasibility): the same algorithm with the reductions ordered as Eigen's run-time-sized
+ * kernels order them (eigen_dynamic_sum, eigen_gemv_dot above). */
+static int colpiv_qr_solve(int n, const double *A, const double *b, double *x, int dynamic)
 {
     double qr[16 * 16], hco[16], nrm_upd[16], nrm_dir[16], tmp[16], c[16];
     int transp[16], perm[16];
@@ -330,7 +416,7 @@ int orc_colpiv_qr_solve(int n, const double *A, const double *b, double *x)
     memcpy(qr, A, sizeof(double) * (size_t)n * n);
 
     for (k = 0; k < n; ++k) {                                       /* :502-507 */
-        nrm_dir[k] = vec_norm(&QR(0, k), n);
+        nrm_dir[k] = vec_norm(&QR(0, k), n, dynamic);
         nrm_upd[k] = nrm_dir[k];
     }
     maxnorm = nrm_upd[0];
@@ -353,7 +439,7 @@ int orc_colpiv_qr_solve(int n, const double *A, const double *b, double *x)
             { double t = nrm_dir[k]; nrm_dir[k] = nrm_dir[big]; nrm_dir[big] = t; }
         }
         /* makeHouseholderInPlace on rows k..n-1 of column k, Householder.h:65-94 */
-        tail_sq = (n - k == 1) ? 0.0 : eigen_squared_norm(&QR(k + 1, k), n - k - 1);
+        tail_sq = (n - k == 1) ? 0.0 : sq_norm(&QR(k + 1, k), n - k - 1, dynamic);
         c0 = QR(k, k);
         if (tail_sq <= DBL_MIN) {
             tau = 0;
@@ -374,9 +460,14 @@ int orc_colpiv_qr_solve(int n, const double *A, const double *b, double *x)
             if (n - k == 1) {
                 /* unreachable for square input (no columns remain), kept for shape */
             } else if (tau != 0) {
+                int as = 0, asz = 0;
+                /* tmp = essential^T * bottom: the vector is the essential part (rows k+1.. of column k), the matrix's
+                 * first row the same rows of column k+1 */
+                if (dynamic) eigen_gemv_split(n * k + k + 1, n * (k + 1) + k + 1, n - k - 1, n - k - 1, &as, &asz);
                 for (j = k + 1; j < n; ++j) {
                     double t = 0.0;
-                    for (i = k + 1; i < n; ++i) t += QR(i, k) * QR(i, j);
+                    if (dynamic) t = eigen_gemv_dot(&QR(k + 1, j), &QR(k + 1, k), n - k - 1, as, asz);
+                    else for (i = k + 1; i < n; ++i) t += QR(i, k) * QR(i, j);
                     t += QR(k, j);
                     tmp[j] = t;
                 }
@@ -393,7 +484,7 @@ int orc_colpiv_qr_solve(int n, const double *A, const double *b, double *x)
                 temp = temp < 0 ? 0 : temp;
                 temp2 = temp * ((nrm_upd[j] / nrm_dir[j]) * (nrm_upd[j] / nrm_dir[j]));
                 if (temp2 <= downdate_thr) {
-                    nrm_dir[j] = (n - k - 1 > 0) ? vec_norm(&QR(k + 1, j), n - k - 1) : 0.0;
+                    nrm_dir[j] = (n - k - 1 > 0) ? vec_norm(&QR(k + 1, j), n - k - 1, dynamic) : 0.0;
                     nrm_upd[j] = nrm_dir[j];
                 } else {
                     nrm_upd[j] *= sqrt(temp);
@@ -415,7 +506,13 @@ int orc_colpiv_qr_solve(int n, const double *A, const double *b, double *x)
             c[k] *= 1.0 - hco[k];
         } else if (hco[k] != 0) {
             double t = 0.0;
-            for (i = k + 1; i < n; ++i) t += QR(i, k) * c[i];
+            if (dynamic) {          /* 1 x 1 inner product: (essential^T .* bottom).sum(), Redux.h */
+                double pr[16];
+                for (i = k + 1; i < n; ++i) pr[i - k - 1] = QR(i, k) * c[i];
+                t = eigen_dynamic_sum(pr, n - k - 1);
+            } else {
+                for (i = k + 1; i < n; ++i) t += QR(i, k) * c[i];
+            }
             t += c[k];
             c[k] -= hco[k] * t;
             for (i = k + 1; i < n; ++i) c[i] -= hco[k] * QR(i, k) * t;
@@ -430,6 +527,9 @@ int orc_colpiv_qr_solve(int n, const double *A, const double *b, double *x)
 #undef QR
     return nonzero_pivots;
 }
+
+int orc_colpiv_qr_solve(int n, const double *A, const double *b, double *x) { return colpiv_qr_solve(n, A, b, x, 0); }
+int orc_colpiv_qr_solve_dynamic(int n, const double *A, const double *b, double *x) { return colpiv_qr_solve(n, A, b, x, 1); }
 
 /* ------------------------------------------------------------------ */
 /* moveInteriorPoint, onedpath_ip.cpp:810-953 (F4: onedpath2_ip.cpp:698-841). */
@@ -519,11 +619,15 @@ void orc_move_toward_feasibility(int variant, double *var)
                 for (k = 0; k < NV; ++k) acc += g[i][k] * g[j][k];
                 a[(size_t)j * n + i] = acc;
             }
-        orc_colpiv_qr_solve(n, a, e, mult);
-        for (k = 0; k < NV; ++k) {
-            double acc = 0.0;
-            for (j = 0; j < n; ++j) acc += g[j][k] * -mult[j];
-            dX[k] = acc;
+        orc_colpiv_qr_solve_dynamic(n, a, e, mult);                   /* :693, MatrixXd: Eigen's dynamic-size kernels */
+        {   /* dX = g^T * -m (:696): a (3 x n) row-major times vector product, alpha = -1; both buffers aligned */
+            int as, asz;
+            eigen_gemv_split(0, 0, n, NV, &as, &asz);
+            for (k = 0; k < NV; ++k) {
+                double col[MAXC];
+                for (j = 0; j < n; ++j) col[j] = g[j][k];
+                dX[k] = -eigen_gemv_dot(col, mult, n, as, asz);
+            }
         }
     }
     for (i = 0; i < NV; ++i) var[i] += dX[i];

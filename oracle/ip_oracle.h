@@ -107,6 +107,9 @@ int    orc_solve_gated(int variant, double *var, double gap_tol, int max_iter);
 
 /* ---- column-pivoted Householder QR solve, any n <= 16, column-major A ---- */
 int    orc_colpiv_qr_solve(int n, const double *A_colmajor, const double *b, double *x);
+/* the same through Eigen's DYNAMIC-size code paths (MatrixXd: moveTowardFeasibility, onedpath_ip.cpp:693): reductions
+   ordered as Redux.h's linear-vectorised traversal and GeneralMatrixVector.h's row-major kernel order them */
+int    orc_colpiv_qr_solve_dynamic(int n, const double *A_colmajor, const double *b, double *x);
 
 /* ---- batches (AoS, stride = orc_state_len) ; threads <= 0 means all cores ---- */
 void   orc_batch_init_feasible(int variant, size_t n, const double *pos0, const double *pos1,

@@ -11,10 +11,20 @@
 // the reference there.  So this file is an operation-for-operation transcription: IEEE
 // divisions and square roots, no fused multiply-adds (the build has -ffp-contract=off and
 // nothing below calls fma_), the accelerations in the reference's expression order
-// (onedpath_ip.cpp:383-391, 424-432), Eigen's squaredNorm packet order, and the
-// rank-revealing column-pivoted Householder QR of ColPivHouseholderQR.h:480-611 /
-// Householder.h:65-131 step by step -- the same sequence oracle/ip_oracle.c restates, which is
-// what the tests compare against bit for bit.
+// (onedpath_ip.cpp:383-391, 424-432), and the rank-revealing column-pivoted Householder QR of
+// ColPivHouseholderQR.h:480-611 / Householder.h:65-131 step by step with every reduction in the order
+// Eigen's DYNAMIC-size kernels use (the reference works on MatrixXd / VectorXd here):
+//   * squaredNorm and the 1 x 1 inner product: Redux.h:209-263, linear-vectorised traversal, SSE2 packets of
+//     two, split independent of the address (esqn_ below);
+//   * essential^T * bottom and g^T * m go through the row-major matrix-vector kernel
+//     (GeneralMatrixVector.h:364-612), which sums scalars up to the vector operand's first 16-byte aligned
+//     element, then packet accumulators, then the scalar tail.  Eigen's buffers are 16-byte aligned, so that
+//     split is a function of the operand's linear offset n k + k + 1 in the n x n matrix: for n <= 4 everything
+//     comes out sequential except (n = 4, k = 0), x1 + (x2 + x3), and the final 4-term g^T m,
+//     (x0 + x2) + (x1 + x3).
+// The same sequence is what oracle/ip_oracle.c restates (orc_colpiv_qr_solve_dynamic), which in turn is pinned bit
+// for bit on the reference's own moveTowardFeasibility compiled in the build container (oracle/_ref), four violated
+// rows (rank-deficient Gram matrix) included; the GPU tests compare against the oracle bit for bit.
 //
 // At most 4 constraints can be violated at once in either variant (F3's come in -a-L / a-L
 // pairs that exclude each other; F4 has 4), so the Gram matrix is at most 4x4 and everything
@@ -34,7 +44,8 @@ template <typename T> __device__ __forceinline__ T tiny_();
 template <> __device__ __forceinline__ double tiny_<double>() { return 2.2250738585072014e-308; }
 template <> __device__ __forceinline__ float tiny_<float>() { return 1.17549435e-38f; }
 
-// Matrix::squaredNorm() of e[0..m) in Eigen 3.3.0's SSE2 order (packets of two doubles, Redux.h):
+// squaredNorm() of e[0..m) in Eigen 3.3.0's SSE2 order (packets of two doubles; the dynamic-size traversal of
+// Redux.h:209-263 and the fixed-size unroller agree up to m = 4):
 // m = 1: s0;  m = 2: s0 + s1;  m = 3: (s0 + s1) + s2;  m = 4: (s0 + s2) + (s1 + s3).
 template <typename T>
 __device__ __forceinline__ T esqn_(T e0, T e1, T e2, T e3, int m)
@@ -117,8 +128,12 @@ __device__ __forceinline__ void colpiv_qr_solve4(int n, T (&A)[4][4], T (&b)[4],
 #pragma unroll
                 for (int j = k + 1; j < N; ++j) {
                     T t = T(0);
+                    if (k == 0 && n == 4) {      // the essential part starts at the odd offset 1: scalar head, then one packet
+                        t = (T(0) + A[1][0] * A[1][j]) + ((T(0) + A[2][0] * A[2][j]) + (T(0) + A[3][0] * A[3][j]));      // accumulators start at 0, as the kernel's
+                    } else {
 #pragma unroll
-                    for (int r = k + 1; r < N; ++r) if (r < n) t = t + A[r][k] * A[r][j];
+                        for (int r = k + 1; r < N; ++r) if (r < n) t = t + A[r][k] * A[r][j];
+                    }
                     tmp[j] = t + A[k][j];
                 }
 #pragma unroll
@@ -248,12 +263,19 @@ __device__ __forceinline__ bool feasibility_move(T dX0, T dX1, T vel0, T vel2, T
         for (int c = 0; c < 4; ++c)
             A[r][c] = ((T(0) + g[r][0] * g[c][0]) + g[r][1] * g[c][1]) + g[r][2] * g[c][2];
     colpiv_qr_solve4<T>(n, A, er, m);
+    // dX = g^T * -m (onedpath_ip.cpp:696): the matrix-vector kernel on aligned operands, alpha = -1
+    if (n == 4) {      // two packets: lanes (x0 + x2, x1 + x3)
+        dxv = -((g[0][0] * m[0] + g[2][0] * m[2]) + (g[1][0] * m[1] + g[3][0] * m[3]));
+        dx0 = -((g[0][1] * m[0] + g[2][1] * m[2]) + (g[1][1] * m[1] + g[3][1] * m[3]));
+        dx1 = -((g[0][2] * m[0] + g[2][2] * m[2]) + (g[1][2] * m[1] + g[3][2] * m[3]));
+    } else {           // n <= 3: one packet and a scalar tail = the sequential sum
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        if (s < n) {
-            dxv = dxv + g[s][0] * -m[s];
-            dx0 = dx0 + g[s][1] * -m[s];
-            dx1 = dx1 + g[s][2] * -m[s];
+        for (int s = 0; s < 3; ++s) {
+            if (s < n) {
+                dxv = dxv + g[s][0] * -m[s];
+                dx0 = dx0 + g[s][1] * -m[s];
+                dx1 = dx1 + g[s][2] * -m[s];
+            }
         }
     }
     return true;

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libip_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libeigen_qr_ref.so")
+REF_HOTPATH_SO = os.path.join(ORACLE_DIR, "_ref", "libref_hotpath.so")
 
 _dp = ctypes.POINTER(ctypes.c_double)
 
@@ -34,8 +35,117 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
+def have_ref_hotpath():
+    return os.path.exists(REF_HOTPATH_SO)
+
+
 def _p(a):
     return a.ctypes.data_as(_dp)
+
+
+class Reference:
+    """The reference's OWN hot-path functions (onedpath_ip.cpp / onedpath2_ip.cpp), compiled in the build container from
+    the files where they lie (oracle/_ref/libref_hotpath.so; recipe: `make -C oracle ref`, harness
+    oracle/ref_build/ref_hotpath.cpp).  This is the pin of the oracle: the restatement is checked against it bit for bit.
+    The library travels to the GPU box prebuilt, so the same class also serves as the `"reference"` CPU baseline there."""
+
+    def __init__(self):
+        if not have_ref_hotpath():
+            raise RuntimeError("oracle/_ref/libref_hotpath.so is not built (make -C oracle ref, needs /root/reference)")
+        self.lib = L = ctypes.CDLL(REF_HOTPATH_SO)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        for v in (3, 4):
+            f = lambda name: getattr(L, "ref%d_%s" % (v, name))      # noqa: E731
+            f("gap").restype = ctypes.c_double
+            f("gap").argtypes = [_dp]
+            f("residual_norm").restype = ctypes.c_double
+            f("residual_norm").argtypes = [_dp, ctypes.c_double]
+            f("constraints_satisfied").argtypes = [_dp]
+            f("constraint").argtypes = [ctypes.c_int, _dp, _dp, _dp]
+            f("constraint_hess").argtypes = [ctypes.c_int, _dp, _dp]
+            f("init_default").argtypes = [_dp]
+            f("step").argtypes = [_dp]
+            f("move_toward_feasibility").argtypes = [_dp]
+            f("print_state").argtypes = [_dp]
+            f("batch_steps").argtypes = [ctypes.c_size_t, _dp, ctypes.c_int]
+            f("batch_solve_gated").restype = ctypes.c_int64
+            f("batch_solve_gated").argtypes = [ctypes.c_size_t, _dp, ctypes.c_double, ctypes.c_int, i32p]
+            f("batch_move_toward_feasibility").argtypes = [ctypes.c_size_t, _dp]
+        L.ref3_init_stuck.argtypes = [_dp]
+        assert L.ref3_state_len() == 16 and L.ref4_state_len() == 12
+        assert L.ref3_num_constraints() == 8 and L.ref4_num_constraints() == 4
+
+    def _f(self, variant, name):
+        return getattr(self.lib, "ref%d_%s" % (variant, name))
+
+    def init_default(self, variant=3):
+        v = np.zeros(Oracle.state_len(variant))
+        self._f(variant, "init_default")(_p(v))
+        return v
+
+    def init_stuck(self):
+        v = np.zeros(16)
+        self.lib.ref3_init_stuck(_p(v))
+        return v
+
+    def gap(self, variant, var):
+        return self._f(variant, "gap")(_p(np.ascontiguousarray(var, dtype=np.float64)))
+
+    def residual_norm(self, variant, var, p):
+        return self._f(variant, "residual_norm")(_p(np.ascontiguousarray(var, dtype=np.float64)), p)
+
+    def satisfied(self, variant, var):
+        return bool(self._f(variant, "constraints_satisfied")(_p(np.ascontiguousarray(var, dtype=np.float64))))
+
+    def constraint(self, variant, i, var):
+        e = np.zeros(1)
+        g = np.zeros(3)
+        self._f(variant, "constraint")(i, _p(np.ascontiguousarray(var, dtype=np.float64)), _p(e), _p(g))
+        return e[0], g
+
+    def constraint_hess(self, variant, i, var):
+        h = np.zeros(9)
+        self._f(variant, "constraint_hess")(i, _p(np.ascontiguousarray(var, dtype=np.float64)), _p(h))
+        return h
+
+    def step(self, variant, var):
+        self._f(variant, "step")(_p(var))
+
+    def move_toward_feasibility(self, variant, var):
+        self._f(variant, "move_toward_feasibility")(_p(var))
+
+    def batch_steps(self, variant, aos, k):
+        assert aos.flags.c_contiguous and aos.dtype == np.float64
+        self._f(variant, "batch_steps")(aos.shape[0], _p(aos), k)
+        return aos
+
+    def batch_solve_gated(self, variant, aos, tol=1e-8, max_iter=200):
+        assert aos.flags.c_contiguous and aos.dtype == np.float64
+        iters = np.zeros(aos.shape[0], dtype=np.int32)
+        total = self._f(variant, "batch_solve_gated")(aos.shape[0], _p(aos), tol, max_iter,
+                                                       iters.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        return iters, total
+
+    def batch_move_toward_feasibility(self, variant, aos):
+        assert aos.flags.c_contiguous and aos.dtype == np.float64
+        self._f(variant, "batch_move_toward_feasibility")(aos.shape[0], _p(aos))
+        return aos
+
+    def print_state(self, variant, var):
+        """The text the reference's printState writes for this state (file descriptor 1 captured)."""
+        import tempfile
+        import sys
+        sys.stdout.flush()
+        with tempfile.TemporaryFile() as tmp:
+            saved = os.dup(1)
+            try:
+                os.dup2(tmp.fileno(), 1)
+                self._f(variant, "print_state")(_p(np.ascontiguousarray(var, dtype=np.float64)))
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+            tmp.seek(0)
+            return tmp.read().decode()
 
 
 class Oracle:
@@ -56,6 +166,7 @@ class Oracle:
         L.orc_init_stuck_f3.argtypes = [_dp]
         L.orc_init_feasible.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp]
         L.orc_colpiv_qr_solve.argtypes = [ctypes.c_int, _dp, _dp, _dp]
+        L.orc_colpiv_qr_solve_dynamic.argtypes = [ctypes.c_int, _dp, _dp, _dp]
         L.orc_batch_init_feasible.argtypes = [ctypes.c_int, ctypes.c_size_t, _dp, _dp, _dp, _dp]
         L.orc_batch_steps.argtypes = [ctypes.c_int, ctypes.c_size_t, _dp, ctypes.c_int, ctypes.c_int]
         L.orc_batch_solve_gated.restype = ctypes.c_int64
@@ -152,11 +263,14 @@ class Oracle:
         self.lib.orc_sample_trajectory(variant, _p(np.ascontiguousarray(var, dtype=np.float64)), _p(pos), _p(acc))
         return pos, acc
 
-    def qr_solve(self, A, b):
+    def qr_solve(self, A, b, dynamic=False):
+        """The oracle's own column-pivoted Householder QR: Eigen's fixed-size order of operations (the Newton step's
+        Matrix<double,11,11>) or, dynamic=True, its run-time-sized one (moveTowardFeasibility's MatrixXd)."""
         n = len(b)
         x = np.zeros(n)
         Ac = np.asfortranarray(A, dtype=np.float64)
-        nz = self.lib.orc_colpiv_qr_solve(n, Ac.ctypes.data_as(_dp), _p(np.ascontiguousarray(b, dtype=np.float64)), _p(x))
+        f = self.lib.orc_colpiv_qr_solve_dynamic if dynamic else self.lib.orc_colpiv_qr_solve
+        nz = f(n, Ac.ctypes.data_as(_dp), _p(np.ascontiguousarray(b, dtype=np.float64)), _p(x))
         return x, nz
 
     def ref_qr_solve(self, A, b, force_dynamic=False):

@@ -399,10 +399,12 @@ def _violating_starts(oracle, variant, n, seed, four):
 @pytest.mark.parametrize("four", [False, True])
 def test_move_toward_feasibility_against_oracle(oracle, variant, four):
     # moveTowardFeasibility, onedpath_ip.cpp:648-721 / onedpath2_ip.cpp:536-609.  The device code is an
-    # operation-for-operation transcription (csrc/feas_core.h), so the comparison is bit for bit -- including the
-    # rank-deficient case (four violated rows, 3 variables), where the reference's own answer hangs on the rounding of a
-    # pivot that is zero in exact arithmetic and no tolerance is meaningful (tests/test_oracle_golden.py pins the
-    # oracle's QR against the reference's Eigen on these systems).
+    # operation-for-operation transcription (csrc/feas_core.h) in the order of Eigen's dynamic-size kernels, so the
+    # comparison is bit for bit -- including the rank-deficient case (four violated rows, 3 variables), where the
+    # reference's own answer hangs on the rounding of a pivot that is zero in exact arithmetic and no tolerance is
+    # meaningful.  The oracle is pinned bit for bit on the reference's own function for 0-4 violated rows
+    # (tests/test_oracle_reference.py); where the compiled reference travelled with the snapshot (oracle/_ref) the GPU
+    # result is compared with it directly as well.
     n = 3000
     aos, nviol = _violating_starts(oracle, variant, n, 5 if four else 11, four)
     with rp.Batch(n, variant) as b:
@@ -420,6 +422,9 @@ def test_move_toward_feasibility_against_oracle(oracle, variant, four):
     err = np.max(np.abs(out[:, :3] - exp[:, :3]) / np.maximum(np.abs(exp[:, :3]), 1.0), axis=1)
     print("feasibility move variant %d four=%s: %d of %d rows differ from the oracle in any bit, max err %.2e" % (variant, four, diff.sum(), n, err.max()))
     assert np.array_equal(out, exp)
+    import oracle_api
+    if oracle_api.have_ref_hotpath():                                 # the reference's own moveTowardFeasibility
+        assert np.array_equal(out, oracle_api.Reference().batch_move_toward_feasibility(variant, aos.copy()))
     assert np.array_equal(out[nviol == 0], aos[nviol == 0])           # nothing violated: no move
     assert np.array_equal(out[:, 3:], aos[:, 3:])                     # multipliers and constants untouched
 
