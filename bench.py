@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no RANK in the environment launches its own N ranks (the parent, before it has
+imported torch or touched HIP, starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process,
+relays rank 0's JSON line and returns the child's exit code); under a launcher it is one of the ranks.
+
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): per GPU a
 batch of 1,048,576 F3 problems (monotone synthetic positions, seed 12345, feasible-start rule
 of SURVEY.md 8d), fp64, each solved until its surrogate duality gap drops below 1e-8 (cap 200
@@ -48,7 +52,7 @@ B_MOVED_F4_F32_ZV = 68.0
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_PEAK_TFLOPS = 78.6   # fp64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 FP32_PEAK_TFLOPS = 157.3  # fp32 vector peak, same guide
-PROFILE_TAG = "r2"        # profiles/<tag>_*.json hold the rocprofv3 counter summaries the file-sourced numbers come from
+PROFILE_TAG = "r3"        # profiles/<tag>_*.json hold the rocprofv3 counter summaries the file-sourced numbers come from
 
 
 def profile_number(fname, *keys):
@@ -123,6 +127,25 @@ def cpu_baseline(sample_n):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` as typed: this process has not imported torch nor touched HIP; it starts the N ranks as a
+    child (torch.distributed.run, one process per GPU), relays what they print and returns their exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RP_BENCH_SELF_LAUNCHED="1")
+    sys.stderr.write("bench.py: --gpus %d without RANK in the environment: starting %d ranks: %s\n" % (n, n, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +159,9 @@ def main():
                          "(RCCL refuses two ranks on one GPU); numbers from such a run are not benchmark results")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -146,9 +172,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available() or rp.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback to time)")
@@ -181,6 +204,7 @@ def main():
     ptrs = [d_pos[j].data_ptr() for j in range(3)]
     for b in batches:
         b.set_problems_device(*ptrs)
+        b.restart()              # init is outside the timed region -- the feasible start is written out here
     lead.sync()
 
     def pass_(index):
@@ -207,7 +231,10 @@ def main():
     t0 = time.perf_counter()
     lead.event_record(0)
     last = lead
+    half = K // 2
     for i in range(W, W + K):
+        if i == W + half and 0 < half < K:
+            lead.event_record(6)         # one extra event: the second half of the launches, timed separately (sustained clocks)
         last = pass_(i)
     lead.event_record(1)
     last.reduce_device(summary.data_ptr())
@@ -217,6 +244,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = lead.event_elapsed_ms(0, 1) / max(K, 1)
+    sustained_ms = lead.event_elapsed_ms(6, 1) / (K - half) if 0 < half < K else kernel_ms
     # every pass solves the same seeded batch from the same start: steps per pass are those of any solved batch
     one = last.reduce()
     steps_local = one["total_steps"] * K
@@ -262,6 +290,8 @@ def main():
         "value": steps_all / elapsed,
         "unit": "Newton steps/s",
         "n_gpus": world,
+        "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,      # what RCCL (torch.distributed "nccl") saw
+        "self_launched": bool(os.environ.get("RP_BENCH_SELF_LAUNCHED")),
         "steps": K,
         "warmup": W,
         "ms_per_step": elapsed / max(K, 1) * 1e3,
@@ -273,7 +303,9 @@ def main():
         "config": {
             "workload": "BASELINE configs[2] (C3): %d F3 onedpath_ip problems per GPU, convergence-gated "
                         "(surrogate gap < 1e-8 checked before every step, cap 200), fp64, monotone seeded positions, "
-                        "feasible-start rule; one fused launch per batch" % args.problems_per_gpu,
+                        "feasible-start rule; one fused launch per batch; start states laid out in HBM, in the batch's scheduled "
+                        "order (precomputed by set_problems), before the timed region -- `end_to_end` times the same batch "
+                        "from bare positions" % args.problems_per_gpu,
             "problems_per_gpu": args.problems_per_gpu,
             "problems_total": n_total,
             "newton_steps_per_pass_per_gpu": steps_per_launch,
@@ -290,13 +322,15 @@ def main():
             "bound": "fp64_valu", "kernel": "k_solve_chunks<double, double, F3> (fused gated solve, one 64-problem chunk of the scheduled order per wave)",
             "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
             "flop_per_newton_step": flop_per_step, "flop_per_newton_step_source": flop_src,
-            "avg_launch_ms": kernel_ms, "newton_steps_per_launch": steps_per_launch,
+            "avg_launch_ms": kernel_ms, "sustained_ms_per_launch": sustained_ms, "newton_steps_per_launch": steps_per_launch,
+            "sustained_newton_steps_per_s": steps_per_launch / (sustained_ms * 1e-3),
             "traffic": traffic, "traffic_source": traffic_src,
             "note": "flop actually executed by the timed kernel (SQ counters of the same kernel on identical problems, per lane-step); "
                     "idle lane-steps of the gated solve (~1 % in the scheduled order) are not counted; traffic = HBM bytes per launch from FETCH_SIZE (x2, "
-                    "calibrated) + WRITE_SIZE: each state crosses HBM once per solve.  A step got cheaper in round 2 (609 -> 533 flop in "
-                    "the fixed-step kernels, 431 in the gated one, which carries its residual sums), so this fraction FALLS while steps/s "
-                    "rise: the vector ALU is issue-saturated either way (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.32 x 3 resident waves)",
+                    "calibrated) + WRITE_SIZE: each state crosses HBM once per solve.  sustained_ms_per_launch = the second half of the K "
+                    "launches (the chip drops its clock after ~2 ms of fp64 load, so the first launches of a run are faster); "
+                    "avg_launch_ms = all K.  A cheaper step shows as a smaller flop fraction at a higher step rate: the vector ALU is "
+                    "issue-saturated either way (valu_issue below is the roof in the unit that binds)",
             # the roof in the unit that binds: wave-level VALU instructions issued per second against one fp64-rate instruction
             # per 4 cycles per SIMD (256 CU x 4 SIMD x 2.4 GHz / 4)
             "valu_issue": valu_issue,
@@ -313,6 +347,39 @@ def main():
         },
     }
 
+    # ---- end to end: bare positions -> solutions, per fresh batch (nothing precomputed), HIP-event timed ----
+    def end_to_end(reps):
+        use = batches[:min(len(batches), reps)]
+        for b in use[:2]:                     # untimed: first-use allocations of the scheduling scratch are long done; clocks
+            b.set_problems_device(*ptrs)
+            b.solve(GAP_TOL, MAX_ITER, 0)
+        lead.sync()
+        lead.event_record(2)
+        for b in use:
+            b.set_problems_device(*ptrs)      # scheduled order + positions into the batch (three kernels), nothing else
+        lead.event_record(3)
+        lead.sync()
+        sched_ms = lead.event_elapsed_ms(2, 3) / len(use)
+        lead.event_record(2)
+        for b in use:
+            b.set_problems_device(*ptrs)
+            b.solve(GAP_TOL, MAX_ITER, 0)     # forms the feasible start in registers, solves, stores
+        lead.event_record(3)
+        lead.sync()
+        ms = lead.event_elapsed_ms(2, 3) / len(use)
+        chk = use[-1].reduce()
+        return {"workload": "per fresh batch of %d problems: rp_batch_set_problems_device (device-resident positions -> scheduled order, "
+                            "k_sched_count / k_sched_scan / k_sched_scatter) + the fused gated solve starting from the feasible start "
+                            "formed in registers (k_solve_chunks<START>); nothing precomputed, no host synchronisation in between" % count,
+                "batches": len(use), "ms_per_batch": ms, "newton_steps_per_s": chk["total_steps"] / (ms * 1e-3),
+                "set_problems_device_ms": sched_ms, "schedule_fraction_of_batch": sched_ms / ms,
+                "newton_steps_per_batch": chk["total_steps"], "converged_fraction": chk["n_converged"] / count,
+                "headline_for_comparison_ms": kernel_ms,
+                "note": "the headline's timed region starts from start states already laid out in scheduled order (SURVEY 8d: init "
+                        "excluded); this block is what a caller pays who hands over positions.  Round 2: 0.500 ms per batch (32.6 G "
+                        "steps/s): rocPRIM sort 0.188 ms + feasible start 0.067 ms + solve 0.245 ms"}
+    line["end_to_end"] = end_to_end(20)
+
     if not args.no_extras:
         # (a) one launch per Newton step: the HBM-streaming form of the same step (216 B really move per step).
         #     cold = every launch on a batch not touched since its init (state comes from HBM);
@@ -324,6 +391,7 @@ def main():
         def reinit():
             for b in spare:
                 b.set_problems_device(*ptrs)
+                b.restart()          # the start state written out: the timed launches below are steps and nothing else
             lead.sync()
             torch.cuda.synchronize()
 
@@ -342,6 +410,7 @@ def main():
         ms_probe = sweep(lambda b: b.step(0))
         del os.environ["RP_STREAM_PROBE"]
         lead.set_problems_device(*ptrs)
+        lead.restart()
         lead.step(1)
         lead.event_record(2)
         for _ in range(len(spare)):
@@ -389,6 +458,7 @@ def main():
             ms = []
             for _ in range(4):
                 c2.set_problems_device(*ptrs)
+                c2.restart()
                 c2.sync()
                 c2.event_record(4)
                 c2.step(50)
@@ -407,6 +477,7 @@ def main():
                 ms50, ms1 = [], []
                 for _ in range(3):
                     c5.set_problems_device(*ptrs)
+                    c5.restart()
                     c5.sync()
                     c5.event_record(4)
                     c5.step(50)
@@ -415,6 +486,7 @@ def main():
                     ms50.append(c5.event_elapsed_ms(4, 5))
                 for _ in range(4):
                     c5.set_problems_device(*ptrs)
+                    c5.restart()
                     c5.sync()
                     c5.event_record(4)
                     c5.step(1)

@@ -38,6 +38,14 @@ extern "C" {
 
 typedef struct rp_batch rp_batch; /* opaque, owned by the caller between create and destroy */
 
+/* ABI revision of this header: bumped whenever a struct that crosses the boundary changes size or an entry point changes
+ * meaning.  rp_abi_version() returns what the LIBRARY was built with; a binding compares the two before its first call
+ * (rocket_path_amd/capi.py and BatchedOneDPathIP do) -- rp_params grew in revision 2 (mu_mode, mu_sigma_try), and a caller
+ * compiled against the older header would have handed rp_batch_set_params a shorter struct.
+ *   1  round 1      2  round 2: rp_params + mu_mode / mu_sigma_try; rp_batch_field_ptr returns batch order (rp_batch_slot_map)
+ *   3  round 3: sizeof(rp_params) returned by rp_params_size(); set_problems defers the feasible start (no visible change) */
+#define RP_ABI_VERSION 3
+
 typedef enum {
     RP_OK = 0,
     RP_ERR_INVALID = 1,     /* bad argument (null handle, unknown variant/dtype, n == 0, ...) */
@@ -65,7 +73,8 @@ typedef enum {
 #define RP_ST_INFEASIBLE 8u /* some c_i > 0 at the last gate check (constraintsSatisfied false) */
 #define RP_ST_STALLED 16u   /* stall detector fired (only when rp_params.stall_window > 0); the problem is left alone from then on */
 #define RP_ST_WRONG_WAY 32u /* with the stall detector on: a gated launch left the problem unconverged with a total duration no smaller than
-                               the one it started the launch with -- F4's "settles the wrong direction" (README.md:34) */
+                               the one it started the launch with -- F4's "settles the wrong direction" (README.md:34).  Cleared again
+                               should a later launch converge the problem */
 
 /* Solver constants, defaults = the reference's compile-time values. */
 typedef struct {
@@ -98,6 +107,8 @@ typedef struct {
 
 /* ---- library ---- */
 RP_API const char *rp_version(void);
+RP_API int rp_abi_version(void);       /* RP_ABI_VERSION of the library's own build */
+RP_API size_t rp_params_size(void);    /* sizeof(rp_params) in the library: must equal the caller's */
 RP_API const char *rp_last_error(void); /* thread-local text of the last failure */
 RP_API const char *rp_status_string(int status);
 RP_API int rp_device_count(int *count);
@@ -140,9 +151,13 @@ RP_API int rp_batch_nudge(rp_batch *b, int var_index, double delta);
 /* k times onKey('n') = moveInteriorPoint (onedpath_ip.cpp:810-953 / onedpath2_ip.cpp:698-841)
  * on every problem, ungated, fused into one launch (state stays in registers between steps). */
 RP_API int rp_batch_step(rp_batch *b, int k);
-/* Diagnostic twin of rp_batch_step: the same k steps (same arithmetic: results are bit-identical to rp_batch_step), returning
- * per problem how often the feasibility loop (onedpath_ip.cpp:927) and the residual loop (:944) halved the step over those k
- * steps.  For decision-level comparisons with the reference; one problem per lane, synchronous, not a fast path. */
+/* Diagnostic twin of rp_batch_step: the same k steps, returning per problem how often the feasibility loop
+ * (onedpath_ip.cpp:927) and the residual loop (:944) halved the step over those k steps.  For decision-level comparisons with
+ * the reference; one problem per lane, synchronous, not a fast path.  Same arithmetic as rp_batch_step; the point (v, t0, t1) it
+ * leaves is bit-identical to rp_batch_step's for every k and variant.  The multipliers are bit-identical too except for F3 once
+ * the point has stopped moving (the reference's post-convergence regime, step ~20 on): there this kernel and the k <= 2
+ * launches evaluate the residual loop on affine pieces, the k >= 3 launches directly, and the multipliers agree to 1e-12
+ * relative, not bit for bit (tests/test_gpu_parity.py, test_launch_shapes_agree_through_the_post_convergence_regime). */
 RP_API int rp_batch_step_counted(rp_batch *b, int k, uint32_t *feas_halvings, uint32_t *resid_halvings);
 /* Gated solve, the convention of SURVEY.md appendix A.5 per problem:
  *     for (it = 0; it < max_iter; ++it) { if (gap < gap_tol) break; step; }

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librp_batch.so")
 
 RP_OK = 0
+ABI_VERSION = 3      # RP_ABI_VERSION of include/rp_batch.h this binding was written against
 RP_ERR_INVALID, RP_ERR_DEVICE, RP_ERR_NOMEM, RP_ERR_UNSUPPORTED, RP_ERR_NO_DEVICE = 1, 2, 3, 4, 5
 VARIANT_F3, VARIANT_F4 = 3, 4
 DTYPE_F64, DTYPE_F32, DTYPE_F32_STATE = 0, 1, 2      # 2: fp32 state in HBM, fp64 arithmetic (include/rp_batch.h)
@@ -41,6 +42,8 @@ _dp = ctypes.POINTER(ctypes.c_double)
 # name -> (restype, argtypes); every symbol include/rp_batch.h declares
 SIGNATURES = {
     "rp_version": (ctypes.c_char_p, []),
+    "rp_abi_version": (ctypes.c_int, []),
+    "rp_params_size": (ctypes.c_size_t, []),
     "rp_last_error": (ctypes.c_char_p, []),
     "rp_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "rp_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
@@ -103,6 +106,9 @@ def load_library(path=None):
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
         fn.restype = res
         fn.argtypes = args
+    if lib.rp_abi_version() != ABI_VERSION or lib.rp_params_size() != ctypes.sizeof(Params):
+        raise RuntimeError("%s was built for ABI revision %d (rp_params of %d bytes); this binding is revision %d (%d bytes): rebuild"
+                           % (p, lib.rp_abi_version(), lib.rp_params_size(), ABI_VERSION, ctypes.sizeof(Params)))
     if path is None:
         _lib = lib
     return lib

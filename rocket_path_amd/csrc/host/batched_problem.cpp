@@ -21,6 +21,12 @@ inline int stateLen(int variant) { return variant == RP_VARIANT_F4 ? 12 : 16; }
 BatchedOneDPathIP::BatchedOneDPathIP(size_t n, int variant, int dtype, int device)
     : batch_(nullptr), n_(n), watched_(0), variant_(variant), repaintHook_(nullptr)
 {
+    // the library this was linked against must speak the header this was compiled against (rp_batch.h, RP_ABI_VERSION)
+    if (rp_abi_version() != RP_ABI_VERSION || rp_params_size() != sizeof(rp_params)) {
+        fprintf(stderr, "BatchedOneDPathIP: librp_batch.so has ABI revision %d (rp_params %zu B), this host was compiled for %d (%zu B)\n",
+                rp_abi_version(), rp_params_size(), RP_ABI_VERSION, sizeof(rp_params));
+        return;      // batch_ stays null: every call becomes a no-op, as after any other failure to create
+    }
     check(rp_batch_create(&batch_, variant, dtype, n, device, nullptr), "rp_batch_create");
 }
 

@@ -9,6 +9,12 @@
 
 namespace rp {
 
+// What the scheduling pass keeps per problem for a batch that has just been given its problems: 32 bytes, one sector.
+struct StartRecord {
+    double pos0, pos1, pos2;
+    long long problem;      // the problem's own index (diagnostic; nothing on the path reads it)
+};
+
 // Device-side view of one batch: `fields` SoA arrays of `n` elements, field f of the problem at POSITION s at
 // base + f * stride + s (stride >= n, an odd multiple of 512 elements: 2-4 KiB aligned fields that do not alias in HBM, rp_batch.cpp).
 struct BatchView {
@@ -22,6 +28,9 @@ struct BatchView {
     uint32_t *status;      // RP_ST_* bits per problem
     uint32_t *slot_of;     // scheduled order (schedule.hip): problem index -> position in the batch ...
     uint32_t *prob_of;     // ... and position -> problem index; both n words, meaningful while `scheduled`
+    StartRecord *records;  // per PROBLEM: the three positions set_problems was given, copied by the scheduling pass; what the
+                           // feasible start -- or the fused solve -- of a fresh batch gathers through prob_of.  Null until the
+                           // first set_problems
     bool scheduled;        // false: the problems lie in problem order (identical problems of initDefault / initStuck)
     unsigned long long *counters;   // 128 words: [0,64) shards of "problems still open after the last gated launch", [64,128) shards of gated steps executed
 };
@@ -44,8 +53,10 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
 hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k, uint32_t *d_nfeas, uint32_t *d_nresid, hipStream_t stream);
 // up to k gated steps per problem (k = max_iter gives the fused solve); zeroes counters[0] first.
 hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream);
-// the fused solve (every problem to its gate in one launch)
-hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, hipStream_t stream);
+// the fused solve (every problem to its gate in one launch).  from_start: the batch holds only its positions (just
+// scheduled, schedule.hip) and every problem begins at its feasible start, formed in registers (reference mode, no stall
+// detector, zero end velocities only)
+hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, bool from_start, hipStream_t stream);
 // max ||r||^2, max gap, #converged, gated steps (+ host_steps) -> d_out4 (device); d_partials has 4 * 1024 doubles.
 hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_steps, double *d_partials,
                          double *d_out4, hipStream_t stream);
@@ -53,17 +64,19 @@ hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_s
 // state movement / initialisation
 hipError_t launch_aos_to_soa(const BatchView &b, const double *d_aos, hipStream_t stream);
 hipError_t launch_soa_to_aos(const BatchView &b, double *d_aos, hipStream_t stream);
-hipError_t launch_init_feasible(const BatchView &b, const HostParams &hp, const double *d_pos0, const double *d_pos1,
-                                const double *d_pos2, hipStream_t stream);
-hipError_t launch_restart_feasible(const BatchView &b, const HostParams &hp, hipStream_t stream);      // same rule, positions already in the batch
+hipError_t launch_restart_feasible(const BatchView &b, const HostParams &hp, hipStream_t stream);      // the feasible start of the positions in the batch's constant fields
+// the same from b.records through b.prob_of (a batch that has just been scheduled): positions into the constant fields, the
+// feasible start, cleared progress words -- everything k_solve_chunks<START> forms in registers, written out
+hipError_t launch_start_from_records(const BatchView &b, const HostParams &hp, hipStream_t stream);
 hipError_t launch_init_const(const BatchView &b, const double *host_state /* state_len values */, hipStream_t stream);
 hipError_t launch_nudge(const BatchView &b, int field, double delta, hipStream_t stream);
 hipError_t launch_clear_progress(const BatchView &b, hipStream_t stream);
-// compute the scheduled order (slot_of / prob_of; schedule.hip) from positions given as three strided double arrays in
-// problem order; d_scratch: schedule_scratch_bytes(n) bytes of device memory
+// compute the scheduled order (slot_of / prob_of; schedule.hip) from positions given as three strided double arrays in problem
+// order, zero the batch's progress counters and -- write_positions -- copy every problem's three positions into b.records;
+// d_scratch: schedule_scratch_bytes(n) bytes of device memory
 hipError_t schedule_scratch_bytes(size_t n, size_t *bytes);
 hipError_t launch_schedule(const BatchView &b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride,
-                           void *d_scratch, size_t scratch_bytes, hipStream_t stream);
+                           bool write_positions, void *d_scratch, size_t scratch_bytes, hipStream_t stream);
 // d_dst[problem] = d_src[position of that problem] for per-problem words kept in batch order (requires b.scheduled)
 hipError_t launch_gather_u32(const BatchView &b, const uint32_t *d_src, uint32_t *d_dst, hipStream_t stream);
 

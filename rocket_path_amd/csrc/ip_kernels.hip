@@ -10,8 +10,9 @@
 //
 // Within the batch the problems lie in SCHEDULED order (schedule.hip, run when positions are set): sorted by what predicts
 // their gated step count, the segment-length ratio min|dX| / max|dX| (64 classes; similar segments take longest) and,
-// within a class, the longer segment's length.  slot_of[] / prob_of[] map problem index <-> position; only the kernels at
-// the ABI boundary (state in / out, read-backs by problem index) look at them, the Newton kernels walk positions.
+// within a class, the longer segment's length (64 levels).  slot_of[] / prob_of[] map problem index <-> position; only the
+// kernels at the ABI boundary (state in / out, read-backs by problem index) and the first kernel after set_problems look at
+// them, the Newton kernels walk positions.
 //
 // Launch shapes, all sharing the per-lane step of ip_core.h:
 //   k_solve_chunks     the gated solve (the benchmark's kernel): one 64-problem chunk of the scheduled order per
@@ -160,6 +161,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
         // 7.07 on the default problem, optimum 4.0) while the gap sticks near 0.47.  With the stall detector on, a problem that
         // stops unconverged with an objective no better than the one this launch started from is flagged.
         if (STALL && kp.stall_window > 0 && steps_here > 0 && !(st & RP_ST_CONVERGED) && !(t0 + t1 < objective_in)) st |= RP_ST_WRONG_WAY;
+        if (st & RP_ST_CONVERGED) st &= ~RP_ST_WRONG_WAY;      // the flag is per launch: a short launch (host-polled rounds) may not lower the objective of a problem that converges later
         if (!(finite_(v) && finite_(t0) && finite_(t1))) st |= RP_ST_NONFINITE;
         if (!all_satisfied<T, VARIANT, Carry>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
         still_open = !done;
@@ -210,11 +212,19 @@ __device__ unsigned long long g_trace[4 * 32768];
 #define RP_TRACE_END(c, steps) do {} while (0)
 #endif
 
+// START: the batch has just been given its problems (rp_batch_set_problems_device: scheduled order computed, each problem's
+// three positions in its 32-byte record, nothing else materialised) and this launch is its first: every lane loads the
+// record of the problem that lies at its position (a gather through prob_of, hidden under the other waves' arithmetic),
+// stores the positions into the constant fields, forms the feasible start (k_restart_feasible's rule, same
+// arithmetic, so the same bits) in registers instead of loading it, takes iteration count and status as zero, and stores
+// unconditionally.  That spares a fresh batch the 128 B per problem the feasible start would write, the 88 B of them this
+// kernel would read back, and the progress words' clearing pass.
 // (mu_mode 1 carries the split direction: ~210 VGPRs, two waves per SIMD)
-template <typename S, typename T, int VARIANT, bool STALL, bool ZV, int MU = 0>
+template <typename S, typename T, int VARIANT, bool STALL, bool ZV, int MU = 0, bool START = false>
 __global__ void __launch_bounds__(64, MU == 1 ? RP_NEWTON_WAVES : RP_GATED_WAVES)
 k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
-               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters)
+               int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
+               const StartRecord *__restrict__ records, const uint32_t *__restrict__ prob_of, double start_limit)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;   // first constant field: pos0, vel0, pos1, pos2, vel2
@@ -225,7 +235,7 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     int it = 0;
     uint32_t st = 0;
     bool active = i < n;
-    if (active) {
+    if (!START && active) {
         it = iters[i];
         st = status[i];
         active = (st & (RP_ST_CONVERGED | RP_ST_MAXITER | RP_ST_STALLED)) == 0;
@@ -236,12 +246,29 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
 
     if (active) {
         S *f = base + i;
-        T v = (T)ld_once(f + 0 * stride), t0 = (T)ld_once(f + 1 * stride), t1 = (T)ld_once(f + 2 * stride);
-        T lam[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) lam[c] = (T)ld_once(f + (3 + c) * stride);
+        T v, t0, t1, lam[NC];
         Prob<T, ZV> pr;
-        {
+        if constexpr (START) {
+            static_assert(ZV, "the feasible start has zero end velocities");
+            typedef double v2 __attribute__((ext_vector_type(2)));
+            const v2 *rec = reinterpret_cast<const v2 *>(records + prob_of[i]);      // the problem that lies here: one 32-byte sector
+            const v2 ra = rec[0], rb = rec[1];
+            const S s0 = (S)ra[0], s1 = (S)ra[1], s2 = (S)rb[0];      // what the constant fields hold from here on
+            f[(CB + 0) * stride] = s0;
+            f[(CB + 2) * stride] = s1;
+            f[(CB + 3) * stride] = s2;
+            const double scale = 3.5 / __builtin_sqrt(12.0);      // k_restart_feasible, operation for operation
+            v = T(0);
+            t0 = (T)(S)(scale * __builtin_sqrt(6.0 * __builtin_fabs((double)s1 - (double)s0) / start_limit));
+            t1 = (T)(S)(scale * __builtin_sqrt(6.0 * __builtin_fabs((double)s2 - (double)s1) / start_limit));
+#pragma unroll
+            for (int c = 0; c < NC; ++c) lam[c] = T(1);
+            pr.dx0 = (T)s1 - (T)s0;
+            pr.dx1 = (T)s2 - (T)s1;
+        } else {
+            v = (T)ld_once(f + 0 * stride); t0 = (T)ld_once(f + 1 * stride); t1 = (T)ld_once(f + 2 * stride);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) lam[c] = (T)ld_once(f + (3 + c) * stride);
             const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
             if constexpr (!ZV) {
                 pr.v0 = (T)f[(CB + 1) * stride];
@@ -256,7 +283,7 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
         asm volatile("" : "+v"(j));
         iters[j] = it;
         status[j] = st;
-        if (steps_here > 0) {
+        if (START || steps_here > 0) {
             S *g = base + j;
             st_once(g + 0 * stride, (S)v);
             st_once(g + 1 * stride, (S)t0);
@@ -762,35 +789,10 @@ k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ slot
     if (i < n) dst[i] = src[slot_of[i]];
 }
 
-// Feasible start (build-defined): vel1 = 0, t_i = (3.5/sqrt 12) sqrt(6 |dX_i| / L),
-// multipliers 1, vel0 = vel2 = 0.  Computed in double, stored in the compute type.
-template <typename T, int VARIANT>
-__global__ void __launch_bounds__(kBlock)
-k_init_feasible(T *__restrict__ base, size_t stride, size_t n, double limit, const double *__restrict__ pos0,
-                const double *__restrict__ pos1, const double *__restrict__ pos2, const uint32_t *__restrict__ prob_of)
-{
-    constexpr int NC = CMap<VARIANT>::NC;
-    constexpr int CB = 3 + NC;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;      // position in the batch
-    if (i >= n) return;
-    const size_t who = prob_of ? (size_t)prob_of[i] : i;             // the problem that lives there
-    const double p0 = pos0[who], p1 = pos1[who], p2 = pos2[who];
-    const double scale = 3.5 / __builtin_sqrt(12.0);
-    T *f = base + i;
-    f[0 * stride] = T(0);
-    f[1 * stride] = (T)(scale * __builtin_sqrt(6.0 * __builtin_fabs(p1 - p0) / limit));
-    f[2 * stride] = (T)(scale * __builtin_sqrt(6.0 * __builtin_fabs(p2 - p1) / limit));
-#pragma unroll
-    for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = T(1);
-    f[(CB + 0) * stride] = (T)p0;
-    f[(CB + 1) * stride] = T(0);
-    f[(CB + 2) * stride] = (T)p1;
-    f[(CB + 3) * stride] = (T)p2;
-    f[(CB + 4) * stride] = T(0);
-}
-
-// The same start rule applied to the positions the batch already holds (its own constant fields): restart without
-// any input crossing the boundary again.
+// Feasible start (build-defined): vel1 = 0, t_i = (3.5/sqrt 12) sqrt(6 |dX_i| / L), multipliers 1,
+// vel0 = vel2 = 0, computed in double from the positions the batch holds in its own constant fields (put there, at each
+// problem's position in the scheduled order, by schedule.hip) and stored in the batch's storage type.  This is what
+// materialises a batch that has been given its problems, and what rp_batch_restart runs.
 template <typename S, int VARIANT>
 __global__ void __launch_bounds__(kBlock)
 k_restart_feasible(S *__restrict__ base, size_t stride, size_t n, double limit)
@@ -809,6 +811,39 @@ k_restart_feasible(S *__restrict__ base, size_t stride, size_t n, double limit)
     for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = S(1);
     f[(CB + 1) * stride] = S(0);
     f[(CB + 4) * stride] = S(0);
+}
+
+// The same start for a batch that has just been scheduled: positions from the 32-byte records the scheduling pass kept per
+// problem (schedule.hip), found through prob_of, into the constant fields, the start computed from the STORED positions exactly as above, progress
+// words cleared -- what k_solve_chunks<START> forms in registers, written out for every other consumer of the state.
+template <typename S, int VARIANT>
+__global__ void __launch_bounds__(kBlock)
+k_start_from_records(S *__restrict__ base, size_t stride, size_t n, double limit, const StartRecord *__restrict__ records,
+                     const uint32_t *__restrict__ prob_of, int32_t *__restrict__ iters, uint32_t *__restrict__ status)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    constexpr int CB = 3 + NC;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const v2 *rec = reinterpret_cast<const v2 *>(records + prob_of[i]);
+    const v2 ra = rec[0], rb = rec[1];
+    const S s0 = (S)ra[0], s1 = (S)ra[1], s2 = (S)rb[0];
+    const double p0 = (double)s0, p1 = (double)s1, p2 = (double)s2;
+    const double scale = 3.5 / __builtin_sqrt(12.0);
+    S *f = base + i;
+    f[0 * stride] = S(0);
+    f[1 * stride] = (S)(scale * __builtin_sqrt(6.0 * __builtin_fabs(p1 - p0) / limit));
+    f[2 * stride] = (S)(scale * __builtin_sqrt(6.0 * __builtin_fabs(p2 - p1) / limit));
+#pragma unroll
+    for (int c = 0; c < NC; ++c) f[(3 + c) * stride] = S(1);
+    f[(CB + 0) * stride] = s0;
+    f[(CB + 1) * stride] = S(0);
+    f[(CB + 2) * stride] = s1;
+    f[(CB + 3) * stride] = s2;
+    f[(CB + 4) * stride] = S(0);
+    iters[i] = 0;
+    status[i] = 0;
 }
 
 // Every problem gets the same state (initDefault / initStuck broadcast).
@@ -1069,33 +1104,37 @@ hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k,
 }
 
 // the gated solve: up to k gated steps per problem, one 64-problem chunk of the scheduled order per single-wave block
-static hipError_t launch_chunks(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream)
+static hipError_t launch_chunks(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, bool from_start, hipStream_t stream)
 {
     const dim3 grid((unsigned)((b.n + 63) / 64)), block(64);
-    if (hp.mu_mode == 1)
+    if (from_start) {      // reference mode, no stall detector, zero end velocities: rp_batch.cpp only asks for this form then
+        if (hp.mu_mode != 0 || hp.stall_window > 0 || !b.zero_end_vel || !b.records) return hipErrorInvalidValue;
+        RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, false, true, 0, true>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
+                                           make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit));
+    } else if (hp.mu_mode == 1)
         RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, true, Z, 1>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
-                                                 make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters));
+                                                 make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit));
     else if (hp.stall_window > 0)
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, true, Z>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
-                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters));
+                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit));
     else
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, false, Z>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
-                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters));
+                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit));
     return hipGetLastError();
 }
 
-hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, hipStream_t stream)
+hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, bool from_start, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
     // (the open-lane shards are not zeroed here: only the host-polled loop reads them, and launch_solve zeroes them itself)
-    return launch_chunks(b, hp, max_iter > 0 ? max_iter : 1, gap_tol, max_iter, stream);
+    return launch_chunks(b, hp, max_iter > 0 ? max_iter : 1, gap_tol, max_iter, from_start, stream);
 }
 
 hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_zero_counter, dim3(1), dim3(kShards), 0, stream, b.counters);
-    return launch_chunks(b, hp, k, gap_tol, max_iter, stream);
+    return launch_chunks(b, hp, k, gap_tol, max_iter, false, stream);
 }
 
 hipError_t launch_gather_u32(const BatchView &b, const uint32_t *d_src, uint32_t *d_dst, hipStream_t stream)
@@ -1147,19 +1186,18 @@ hipError_t launch_soa_to_aos_range(const BatchView &b, size_t first, size_t coun
 
 hipError_t launch_soa_to_aos(const BatchView &b, double *d_aos, hipStream_t stream) { return launch_soa_to_aos_range(b, 0, b.n, d_aos, stream); }
 
-hipError_t launch_init_feasible(const BatchView &b, const HostParams &hp, const double *d_pos0, const double *d_pos1,
-                                const double *d_pos2, hipStream_t stream)
-{
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_init_feasible<S, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
-                                       (S *)b.base, b.stride, b.n, hp.accel_limit, d_pos0, d_pos1, d_pos2,
-                                       b.scheduled ? (const uint32_t *)b.prob_of : (const uint32_t *)nullptr));
-    return hipGetLastError();
-}
-
 hipError_t launch_restart_feasible(const BatchView &b, const HostParams &hp, hipStream_t stream)
 {
     RP_DISPATCH(b, hipLaunchKernelGGL((k_restart_feasible<S, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
                                        (S *)b.base, b.stride, b.n, hp.accel_limit));
+    return hipGetLastError();
+}
+
+hipError_t launch_start_from_records(const BatchView &b, const HostParams &hp, hipStream_t stream)
+{
+    if (!b.records) return hipErrorInvalidValue;
+    RP_DISPATCH(b, hipLaunchKernelGGL((k_start_from_records<S, V>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream,
+                                       (S *)b.base, b.stride, b.n, hp.accel_limit, (const StartRecord *)b.records, (const uint32_t *)b.prob_of, b.iters, b.status));
     return hipGetLastError();
 }
 

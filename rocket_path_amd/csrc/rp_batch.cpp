@@ -13,7 +13,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <new>
 
 #include "ip_kernels.h"
@@ -29,9 +28,10 @@ struct rp_batch {
     double *d_pos;            // lazily allocated 3 * n doubles (set_problems staging)
     double *d_range;          // lazily allocated kRangeChunk * kRangeRow doubles: staging of the *_range read-backs
     uint32_t *d_words;        // lazily allocated 2 n words: per-problem words gathered from batch order into problem order
-    void *d_sched;            // lazily allocated scratch of the scheduling sort (schedule.hip), sched_bytes bytes
+    void *d_sched;            // lazily allocated scratch of the scheduling pass (schedule.hip), sched_bytes bytes
     size_t sched_bytes;
-    hipEvent_t sched_ready, sched_done;      // order the sort (helper queue) against this batch's stream; created with d_sched
+    bool at_start;            // set_problems has run and nothing else since: the batch holds its scheduled order and its positions; the
+                              // feasible start itself (mutable fields, progress words) is NOT materialised yet -- see materialize()
     double ungated_steps;     // per-problem count of ungated steps since the last init
     unsigned long long *h_pinned;   // 72 pinned host words: [0,64) counter shards, [64,68) reduction: read-backs without pageable staging
     hipEvent_t events[8];
@@ -91,38 +91,45 @@ int reset_progress(rp_batch *b)
     return RP_OK;
 }
 
-// one helper queue per device for the scheduling sort (see schedule)
-struct SchedQueue {
-    std::mutex lock;
-    hipStream_t stream = nullptr;
-};
-constexpr int kMaxDevices = 64;
-SchedQueue g_sched[kMaxDevices];
-
-// the scheduled order from positions given as three strided double arrays in problem order (device memory)
-int schedule(rp_batch *b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride)
+// the scheduled order from positions given as three strided double arrays in problem order (device memory), on the batch's
+// own stream (three small kernels of ours, schedule.hip; round 2's library sort needed a queue of its own)
+int schedule(rp_batch *b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride, bool write_positions)
 {
     if (!b->d_sched) {
-        RP_HIP(rp::schedule_scratch_bytes(b->view.n, &b->sched_bytes));
-        RP_HIP(hipMalloc(&b->d_sched, b->sched_bytes));
-        RP_HIP(hipEventCreateWithFlags(&b->sched_ready, hipEventDisableTiming));
-        RP_HIP(hipEventCreateWithFlags(&b->sched_done, hipEventDisableTiming));
+        size_t bytes = 0;
+        RP_HIP(rp::schedule_scratch_bytes(b->view.n, &bytes));
+        void *p = nullptr;
+        RP_HIP(hipMalloc(&p, bytes));
+        b->d_sched = p;
+        b->sched_bytes = bytes;
     }
-    // The sort runs on a queue of its own, ordered against the batch's stream by two events.  Measured
-    // (profiles/probes/fixed50_order_probe.py): after rocPRIM's sort kernels have run on a queue, a later kernel on THAT
-    // queue with one wave per SIMD runs 40 % slower (65,536 x 50 steps: 0.46 ms against 0.33) until the next long kernel
-    // has passed; other queues are unaffected.  One helper stream per device, shared by its batches (setup work only).
-    SchedQueue &q = g_sched[b->device % kMaxDevices];
-    std::lock_guard<std::mutex> hold(q.lock);
-    if (!q.stream) RP_HIP(hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
-    RP_HIP(hipEventRecord(b->sched_ready, b->stream));          // the positions are where the caller's stream order says they are
-    RP_HIP(hipStreamWaitEvent(q.stream, b->sched_ready, 0));
-    RP_HIP(rp::launch_schedule(b->view, d_pos0, d_pos1, d_pos2, pstride, b->d_sched, b->sched_bytes, q.stream));
-    RP_HIP(hipEventRecord(b->sched_done, q.stream));
-    RP_HIP(hipStreamWaitEvent(b->stream, b->sched_done, 0));
+    if (write_positions && !b->view.records) {      // 32 B per problem: what the scheduling pass keeps for the feasible start / the fused solve
+        void *p = nullptr;
+        RP_HIP(hipMalloc(&p, b->view.n * sizeof(rp::StartRecord)));
+        b->view.records = (rp::StartRecord *)p;
+    }
+    RP_HIP(rp::launch_schedule(b->view, d_pos0, d_pos1, d_pos2, pstride, write_positions, b->d_sched, b->sched_bytes, b->stream));
     b->view.scheduled = true;
     return RP_OK;
 }
+
+// set_problems leaves the batch "at its start" without writing the start: the fused gated solve forms it in registers
+// (k_solve_chunks<START>).  Every other consumer of the state goes through here first: positions from the records into the
+// constant fields, their feasible start, cleared progress words -- bit for bit what the fused solve starts from.
+int materialize(rp_batch *b)
+{
+    if (!b->at_start) return RP_OK;
+    b->at_start = false;
+    RP_HIP(rp::launch_start_from_records(b->view, b->params, b->stream));      // (the progress counters were zeroed by the scheduling pass)
+    return RP_OK;
+}
+
+#define RP_NEED_STATE(b)                     \
+    do {                                     \
+        RP_NEED(b);                          \
+        const int ms_ = materialize(b);      \
+        if (ms_ != RP_OK) return ms_;        \
+    } while (0)
 
 int need_words(rp_batch *b)
 {
@@ -153,7 +160,9 @@ int need_aos(rp_batch *b)
 
 extern "C" {
 
-const char *rp_version(void) { return "rocket_path_amd 0.3 (gfx950)"; }
+const char *rp_version(void) { return "rocket_path_amd 0.4 (gfx950)"; }
+int rp_abi_version(void) { return RP_ABI_VERSION; }
+size_t rp_params_size(void) { return sizeof(rp_params); }
 const char *rp_last_error(void) { return g_err; }
 
 const char *rp_status_string(int status)
@@ -263,10 +272,9 @@ int rp_batch_destroy(rp_batch *b)
     if (b->view.status) (void)hipFree(b->view.status);
     if (b->view.slot_of) (void)hipFree(b->view.slot_of);
     if (b->view.prob_of) (void)hipFree(b->view.prob_of);
+    if (b->view.records) (void)hipFree(b->view.records);
     if (b->d_words) (void)hipFree(b->d_words);
     if (b->d_sched) (void)hipFree(b->d_sched);
-    if (b->sched_ready) (void)hipEventDestroy(b->sched_ready);
-    if (b->sched_done) (void)hipEventDestroy(b->sched_done);
     if (b->view.counters) (void)hipFree(b->view.counters);
     if (b->d_scratch) (void)hipFree(b->d_scratch);
     if (b->h_pinned) (void)hipHostFree(b->h_pinned);
@@ -349,6 +357,7 @@ int rp_batch_init_default(rp_batch *b)
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
     b->view.zero_end_vel = true;
     b->view.scheduled = false;         // identical problems: nothing to schedule
+    b->at_start = false;
     return reset_progress(b);
 }
 
@@ -363,6 +372,7 @@ int rp_batch_init_stuck(rp_batch *b)
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
     b->view.zero_end_vel = true;
     b->view.scheduled = false;
+    b->at_start = false;
     return reset_progress(b);
 }
 
@@ -370,17 +380,26 @@ int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double
 {
     RP_NEED(b);
     if (!d_pos0 || !d_pos1 || !d_pos2) return fail(RP_ERR_INVALID, "null position array");
-    // where each problem goes (scheduled order, ip_kernels.hip), then the feasible start of the problem at each position
-    int st = schedule(b, d_pos0, d_pos1, d_pos2, 1);
+    // Where each problem goes (scheduled order), its positions copied into its record, progress counters zeroed: three
+    // kernels (schedule.hip).  The feasible start itself is not written: a fused gated solve that follows forms it in registers,
+    // anything else materialises it first (materialize above).  The position arrays are consumed in stream order, here.
+    if (!b->view.zero_end_vel) {       // a set_state / nudge / field_ptr may have left non-zero end velocities: the start rule zeroes them
+        const size_t es = elem_size(b->view.dtype), cb = 3 + (size_t)rp::num_constraints(b->view.variant);
+        RP_HIP(hipMemsetAsync((char *)b->view.base + (cb + 1) * b->view.stride * es, 0, b->view.n * es, b->stream));
+        RP_HIP(hipMemsetAsync((char *)b->view.base + (cb + 4) * b->view.stride * es, 0, b->view.n * es, b->stream));
+    }
+    int st = schedule(b, d_pos0, d_pos1, d_pos2, 1, true);
     if (st != RP_OK) return st;
-    RP_HIP(rp::launch_init_feasible(b->view, b->params, d_pos0, d_pos1, d_pos2, b->stream));
     b->view.zero_end_vel = true;       // the feasible-start rule sets vel0 = vel2 = 0
-    return reset_progress(b);
+    b->ungated_steps = 0.0;
+    b->at_start = true;
+    return RP_OK;
 }
 
 int rp_batch_restart(rp_batch *b)
 {
     RP_NEED(b);
+    if (b->at_start) return materialize(b);      // already at the start of its positions: write it out
     RP_HIP(rp::launch_restart_feasible(b->view, b->params, b->stream));
     b->view.zero_end_vel = true;
     b->ungated_steps = 0.0;
@@ -419,8 +438,9 @@ int rp_batch_set_state(rp_batch *b, const double *aos)
     RP_HIP(hipMemcpyAsync(b->d_aos, aos, bytes, hipMemcpyHostToDevice, b->stream));
     {   // schedule by the positions in the rows (columns pos0, pos1, pos2 of the reference's enum), then scatter the rows
         const size_t cb = 3 + (size_t)rp::num_constraints(b->view.variant);
-        st = schedule(b, b->d_aos + cb + 0, b->d_aos + cb + 2, b->d_aos + cb + 3, M);
+        st = schedule(b, b->d_aos + cb + 0, b->d_aos + cb + 2, b->d_aos + cb + 3, M, false);
         if (st != RP_OK) return st;
+        b->at_start = false;      // the rows below are the state
     }
     RP_HIP(rp::launch_aos_to_soa(b->view, b->d_aos, b->stream));
     st = reset_progress(b);
@@ -431,7 +451,7 @@ int rp_batch_set_state(rp_batch *b, const double *aos)
 
 int rp_batch_get_state(rp_batch *b, double *aos)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     if (!aos) return fail(RP_ERR_INVALID, "null state array");
     int st = need_aos(b);
     if (st != RP_OK) return st;
@@ -444,7 +464,7 @@ int rp_batch_get_state(rp_batch *b, double *aos)
 
 int rp_batch_get_state_range(rp_batch *b, size_t first, size_t count, double *aos)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     int st = check_range(b, first, count, aos);
     if (st == RP_OK) st = need_range(b);
     if (st != RP_OK) return st;
@@ -460,7 +480,7 @@ int rp_batch_get_state_range(rp_batch *b, size_t first, size_t count, double *ao
 
 int rp_batch_nudge(rp_batch *b, int var_index, double delta)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     if (var_index < 0 || var_index >= rp::state_len(b->view.variant)) return fail(RP_ERR_INVALID, "variable index %d out of range", var_index);
     RP_HIP(rp::launch_nudge(b->view, var_index, delta, b->stream));
     {
@@ -472,7 +492,7 @@ int rp_batch_nudge(rp_batch *b, int var_index, double delta)
 
 int rp_batch_step(rp_batch *b, int k)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     if (k < 0 || k > 1000000) return fail(RP_ERR_INVALID, "step count %d out of range (0..1000000)", k);
     // k == 0 is a no-op, except under RP_STREAM_PROBE=1 where it launches the step kernel with no
     // steps: the same 16 loads and 11 stores per problem and nothing else (bandwidth calibration).
@@ -484,7 +504,7 @@ int rp_batch_step(rp_batch *b, int k)
 
 int rp_batch_step_counted(rp_batch *b, int k, uint32_t *feas_halvings, uint32_t *resid_halvings)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     if (k < 0 || k > 1000000) return fail(RP_ERR_INVALID, "step count %d out of range (0..1000000)", k);
     if (!feas_halvings || !resid_halvings) return fail(RP_ERR_INVALID, "null output");
     if (b->params.mu_mode != 0) return fail(RP_ERR_UNSUPPORTED, "the counted step exists for the reference's mu mode only");
@@ -514,9 +534,14 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
     if (max_iter < 0 || max_iter > 1000000) return fail(RP_ERR_INVALID, "max_iter %d out of range (0..1000000)", max_iter);
     if (!(gap_tol == gap_tol)) return fail(RP_ERR_INVALID, "gap_tol is NaN");
     if (steps_per_launch <= 0) {
-        RP_HIP(rp::launch_solve_fused(b->view, b->params, gap_tol, max_iter, b->stream));
+        // a batch that has just been given its problems starts from the feasible start formed in registers (reference mode only)
+        const bool from_start = b->at_start && b->params.mu_mode == 0 && b->params.stall_window == 0 && b->view.zero_end_vel && max_iter > 0;
+        if (from_start) b->at_start = false;
+        else { const int ms = materialize(b); if (ms != RP_OK) return ms; }
+        RP_HIP(rp::launch_solve_fused(b->view, b->params, gap_tol, max_iter, from_start, b->stream));
         return RP_OK;
     }
+    { const int ms = materialize(b); if (ms != RP_OK) return ms; }
     // bounded host loop: every launch either finishes a problem or advances it by >= 1 step
     const int max_launches = max_iter / steps_per_launch + 2;
     for (int l = 0; l < max_launches; ++l) {
@@ -532,7 +557,7 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
 
 int rp_batch_solve_launch(rp_batch *b, double gap_tol, int max_iter, int k)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     if (max_iter < 0 || max_iter > 1000000) return fail(RP_ERR_INVALID, "max_iter %d out of range (0..1000000)", max_iter);
     if (k < 1 || k > 1000000) return fail(RP_ERR_INVALID, "steps per launch %d out of range (1..1000000)", k);
     if (!(gap_tol == gap_tol)) return fail(RP_ERR_INVALID, "gap_tol is NaN");
@@ -542,14 +567,14 @@ int rp_batch_solve_launch(rp_batch *b, double gap_tol, int max_iter, int k)
 
 int rp_batch_move_toward_feasibility(rp_batch *b)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     RP_HIP(rp::launch_move_toward_feasibility(b->view, b->params, b->stream));
     return RP_OK;
 }
 
 int rp_batch_get_iters(rp_batch *b, int32_t *iters, uint32_t *status)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     const size_t n = b->view.n;
     const uint32_t *src_it = reinterpret_cast<const uint32_t *>(b->view.iters), *src_st = b->view.status;
     if (b->view.scheduled) {      // the words lie in batch order
@@ -572,7 +597,7 @@ int rp_batch_get_iters(rp_batch *b, int32_t *iters, uint32_t *status)
 
 int rp_batch_reduce_device(rp_batch *b, double *d_out4)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     if (!d_out4) return fail(RP_ERR_INVALID, "null output");
     RP_HIP(rp::launch_reduce(b->view, b->params, b->ungated_steps * (double)b->view.n, b->d_scratch, d_out4, b->stream));
     return RP_OK;
@@ -620,7 +645,7 @@ int rp_batch_summary_read(rp_batch *b, rp_reduction *out)
 
 int rp_batch_sample(rp_batch *b, double *pos66, double *acc4)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     if (!pos66 || !acc4) return fail(RP_ERR_INVALID, "null output");
     const size_t n = b->view.n;
     double *d = nullptr;
@@ -636,7 +661,7 @@ int rp_batch_sample(rp_batch *b, double *pos66, double *acc4)
 
 int rp_batch_sample_range(rp_batch *b, size_t first, size_t count, double *pos66, double *acc4)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     int st = check_range(b, first, count, pos66);
     if (st == RP_OK && !acc4) st = fail(RP_ERR_INVALID, "null output");
     if (st == RP_OK) st = need_range(b);
@@ -654,7 +679,7 @@ int rp_batch_sample_range(rp_batch *b, size_t first, size_t count, double *pos66
 
 int rp_batch_constraints_range(rp_batch *b, size_t first, size_t count, double *rows)
 {
-    RP_NEED(b);
+    RP_NEED_STATE(b);
     int st = check_range(b, first, count, rows);
     if (st == RP_OK) st = need_range(b);
     if (st != RP_OK) return st;
@@ -708,6 +733,11 @@ int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr)
 {
     if (!b || !d_ptr) return fail(RP_ERR_INVALID, "null argument");
     if (field < 0 || field >= rp::state_len(b->view.variant)) return fail(RP_ERR_INVALID, "field %d out of range", field);
+    {   // the caller is about to look at (or write) raw state: it has to exist
+        RP_HIP(hipSetDevice(b->device));
+        const int ms = materialize(b);
+        if (ms != RP_OK) return ms;
+    }
     *d_ptr = (char *)b->view.base + (size_t)field * b->view.stride * elem_size(b->view.dtype);
     {   // a caller holding a raw pointer to an end-velocity field may write non-zero values the batch never sees: from
         // here on (until the next init / set_problems / set_state) the Newton kernels read vel0X and vel2X

@@ -1,83 +1,241 @@
 // schedule.hip -- the scheduled order of a batch (gfx950): where each problem lies inside the field arrays.
 //
 // The gated solve gives every wave 64 consecutive positions of the batch (ip_kernels.hip, k_solve_chunks) and a wave
-// runs until its slowest lane has converged, so the problems are kept sorted by what predicts their gated step count.
-// Measured on the benchmark distribution (oracle step counts of 1,048,576 problems): the count is a function of the
-// segment-length ratio r = min|dX| / max|dX| (14 steps for r < 0.5 rising to 18 at r = 1) and, within a ratio class, of
-// the longer segment's length; sorted by (class of r, length) the step counts inside a 64-problem chunk differ by 0.34 on
-// average and 1.0 % of the lane-steps are idle (batch order: 19.2 %; ratio alone: 3.2 %).
+// runs until its slowest lane has converged, so the problems are kept grouped by what predicts their gated step count.
+// Measured on the benchmark distribution (oracle step counts of 1,048,576 problems, tests/checks/idle_lanes.py): the count
+// is a function of the segment-length ratio r = min|dX| / max|dX| (14 steps for r < 0.5 rising to 18 at r = 1) and, within a
+// ratio class, of the longer segment's length.  A 12-bit key -- 64 ratio classes x 64 length levels, 8 per octave over
+// [4, 1024), clamped outside -- leaves 1.2 % of the lane-steps idle (batch order: 19.2 %; the 32-bit key round 2 sorted on:
+// 1.0 %; 8,192 bins: 0.9 %).
 //
-// This runs when positions are set (set_problems / set_state), never per solve: one key per problem, one stable radix
-// sort of (key, problem index) pairs -- rocPRIM through hipCUB, a library sort being the right tool for a one-off
-// setup step -- and the inverse map.  Ties keep problem order, so the order is a pure function of the positions.
+// With 4,096 possible keys the order is ONE stable counting sort, three small hand-written kernels on the batch's own
+// stream (round 2 called rocPRIM's 32-bit radix sort here: 23 dispatches and 188 us at 1 Mi problems for an order whose
+// only purpose is to save ~30 us of the solve):
+//   k_sched_count    per 4,096-problem tile: key of every problem (kept, 2 B), histogram in LDS -> hist[tile][key]; for
+//                    set_problems also the problem's three positions as one 32-byte record, in PROBLEM order (coalesced):
+//                    the caller's arrays are not needed after this kernel
+//   k_sched_scan     per key: exclusive prefix over the tiles (in place) and the key's total
+//   k_sched_scatter  per tile: base of every key (prefix of the totals) + the tile's prefix + a stable rank inside the tile
+//                    -> position of every problem; writes slot_of[problem] (coalesced) and prob_of[position] (4 B scattered:
+//                    the only scattered access of the pass)
+// Nothing else moves: the consumer of a fresh batch -- the fused solve, or the kernel that writes the feasible start out --
+// finds its problem through prob_of and reads that problem's record (one aligned 32-byte sector).  In the solve that gather
+// rides under the arithmetic of the other resident waves.  Measured alternatives at 1 Mi problems
+// (profiles/r3_sched_probe.log): scattering the three positions into the SoA constant fields at their position (3 x 8 B per
+// problem, partial sectors) +35 us, scattering 32-byte records +17 us, the 4-byte inverse map +5 us.
+// Ties keep problem order (stable at every level: tiles in order, waves of a tile in order, 64-problem groups of a wave in
+// order, lanes by a match-any rank), so the order is a pure function of the positions.
 #include "ip_kernels.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 namespace rp {
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kThreads = 256;                 // 4 waves
+constexpr int kPerThread = 16;
+constexpr int kTileProblems = kThreads * kPerThread;      // 4,096 problems per tile
+constexpr int kKeys = 4096;                   // 64 ratio classes x 64 length levels
+constexpr int kWaves = kThreads / 64;
+constexpr int kWaveSpan = kTileProblems / kWaves;         // consecutive problems a wave owns: 1,024 = 16 groups of 64
 
-// key = ratio class (6 bits) : the longer segment's length as the top 26 bits of its float pattern (monotone for
-// positive floats).  Equal segments, zero-length pairs and NaN go to the last class.
-__global__ void __launch_bounds__(kBlock)
-k_schedule_keys(const double *__restrict__ pos0, const double *__restrict__ pos1, const double *__restrict__ pos2, size_t pstride,
-                size_t n, uint32_t *__restrict__ keys, uint32_t *__restrict__ index)
+// key = ratio class (6 bits) : length level (6 bits).  Level = 8 per octave of the longer segment's length from 4 upwards
+// (exponent and top three mantissa bits of its float pattern), clamped to [0, 63].  Equal segments, zero-length pairs and
+// NaN go to the last class.
+__device__ __forceinline__ uint32_t schedule_key(double p0, double p1, double p2)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const size_t at = i * pstride;
-    const double d0 = __builtin_fabs(pos1[at] - pos0[at]), d1 = __builtin_fabs(pos2[at] - pos1[at]);
+    const double d0 = __builtin_fabs(p1 - p0), d1 = __builtin_fabs(p2 - p1);
     const double lo = d0 < d1 ? d0 : d1, hi = d0 < d1 ? d1 : d0;
     const double r = lo / hi * 64.0;
     const uint32_t cls = (r >= 0.0 && r < 64.0) ? (uint32_t)r : 63u;
     const float len = (float)hi;
-    const uint32_t bits = (len == len && len > 0.0f) ? (__float_as_uint(len) >> 5) : 0u;      // < 2^26 (inf: 0x3FC0000)
-    keys[i] = (cls << 26) | bits;
-    index[i] = (uint32_t)i;
+    int lvl = 0;
+    if (len == len && len > 0.0f) lvl = (int)(__float_as_uint(len) >> 20) - ((127 + 2) << 3);      // 8 * (log2 floor - 2) + 3 mantissa bits
+    lvl = lvl < 0 ? 0 : lvl > 63 ? 63 : lvl;
+    return (cls << 6) | (uint32_t)lvl;
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_invert(const uint32_t *__restrict__ prob_of, size_t n, uint32_t *__restrict__ slot_of)
+template <bool RECORDS>
+__global__ void __launch_bounds__(kThreads)
+k_sched_count(const double *__restrict__ pos0, const double *__restrict__ pos1, const double *__restrict__ pos2, size_t pstride,
+              size_t n, uint32_t *__restrict__ hist, uint16_t *__restrict__ keys, StartRecord *__restrict__ records,
+              unsigned long long *__restrict__ counters)
 {
-    const size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (s < n) slot_of[prob_of[s]] = (uint32_t)s;
+    __shared__ uint32_t s_cnt[kKeys];
+    for (int k = threadIdx.x; k < kKeys; k += kThreads) s_cnt[k] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 128 && counters) counters[threadIdx.x] = 0;      // the batch's progress counters: a new problem set
+    __syncthreads();
+    const size_t first = (size_t)blockIdx.x * kTileProblems;
+    double p0[kPerThread], p1[kPerThread], p2[kPerThread];
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+        const size_t i = first + (size_t)q * kThreads + threadIdx.x;      // any assignment of problems to threads: only the counts matter
+        const size_t at = (i < n ? i : 0) * pstride;
+        p0[q] = pos0[at]; p1[q] = pos1[at]; p2[q] = pos2[at];
+    }
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+        const size_t i = first + (size_t)q * kThreads + threadIdx.x;
+        if (i < n) {
+            const uint32_t key = schedule_key(p0[q], p1[q], p2[q]);
+            atomicAdd(&s_cnt[key], 1u);
+            keys[i] = (uint16_t)key;
+            if constexpr (RECORDS) {
+                typedef double v2 __attribute__((ext_vector_type(2)));
+                v2 *rec = reinterpret_cast<v2 *>(records + i);
+                const v2 a = {p0[q], p1[q]}, b = {p2[q], __longlong_as_double((long long)i)};
+                __builtin_nontemporal_store(a, rec);
+                __builtin_nontemporal_store(b, rec + 1);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *row = hist + (size_t)blockIdx.x * kKeys;
+    for (int k = threadIdx.x; k < kKeys; k += kThreads) row[k] = s_cnt[k];
+}
+
+// hist[tile][key] -> exclusive prefix over the tiles, per key, in place; total[key].  A block owns 16 keys (one 64-byte
+// segment of every row); its 256 threads are 16 keys x 16 groups of consecutive rows.
+__global__ void __launch_bounds__(kThreads)
+k_sched_scan(uint32_t *__restrict__ hist, unsigned ntiles, uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t s_seg[16][17];
+    const unsigned key = blockIdx.x * 16 + (threadIdx.x & 15);
+    const unsigned g = threadIdx.x >> 4;
+    const unsigned per = (ntiles + 15) / 16;
+    const unsigned r0 = g * per, r1 = (r0 + per < ntiles) ? r0 + per : ntiles;
+    uint32_t sum = 0;
+    for (unsigned r = r0; r < r1; ++r) sum += hist[(size_t)r * kKeys + key];
+    s_seg[g][threadIdx.x & 15] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (unsigned q = 0; q < g; ++q) run += s_seg[q][threadIdx.x & 15];
+    if (g == 15) total[key] = run + sum;
+    for (unsigned r = r0; r < r1; ++r) {
+        const size_t at = (size_t)r * kKeys + key;
+        const uint32_t v = hist[at];
+        hist[at] = run;
+        run += v;
+    }
+}
+
+// lanes of the wave that hold the same 12-bit key as this lane
+__device__ __forceinline__ unsigned long long match_key(uint32_t key)
+{
+    unsigned long long peers = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit < 12; ++bit) {
+        const bool set = (key >> bit) & 1u;
+        const unsigned long long b = __ballot(set);
+        peers &= set ? b : ~b;
+    }
+    return peers;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_sched_scatter(const uint16_t *__restrict__ keys, size_t n, const uint32_t *__restrict__ hist, const uint32_t *__restrict__ total,
+                uint32_t *__restrict__ slot_of, uint32_t *__restrict__ prob_of)
+{
+    __shared__ uint32_t s_off[kKeys];                 // position of the tile's first problem with this key
+    __shared__ uint32_t s_wave[kWaves][kKeys / 2];    // per wave and key: problems of earlier waves and groups of the tile (two 16-bit counts per word)
+    __shared__ uint32_t s_part[kThreads];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int k = tid; k < kWaves * (kKeys / 2); k += kThreads) (&s_wave[0][0])[k] = 0;
+    __syncthreads();
+
+    // this wave's problems, in order: group q = problems [first + w * 1024 + 64 q, + 64)
+    const size_t first = (size_t)blockIdx.x * kTileProblems + (size_t)w * kWaveSpan;
+    uint32_t key[kPerThread];
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+        const size_t i = first + (size_t)q * 64 + lane;
+        key[q] = i < n ? (uint32_t)keys[i] : 0xfffu;
+    }
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+        const size_t i = first + (size_t)q * 64 + lane;
+        if (i < n) atomicAdd(&s_wave[w][key[q] >> 1], 1u << (16 * (key[q] & 1u)));      // <= 1,024 per wave and key: fits 16 bits
+    }
+
+    // base of every key = exclusive prefix of the totals (each tile recomputes it: 16 KiB from L2) + this tile's prefix
+    {
+        uint32_t t[16], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { t[j] = total[tid * 16 + j]; sum += t[j]; }
+        s_part[tid] = sum;
+        __syncthreads();                               // also: every wave's counts are in s_wave
+        uint32_t run = 0;
+        for (int j = 0; j < tid; ++j) run += s_part[j];
+        const uint32_t *row = hist + (size_t)blockIdx.x * kKeys + tid * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = tid * 16 + j;
+            s_off[k] = run + row[j];
+            run += t[j];
+            // per-wave counts -> exclusive prefix over the waves (in place, both halves of the word at once)
+            if ((k & 1) == 0) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int v = 0; v < kWaves; ++v) { const uint32_t c = s_wave[v][k >> 1]; s_wave[v][k >> 1] = acc; acc += c; }
+            }
+        }
+    }
+    __syncthreads();
+
+    // stable rank, group by group: lanes with the same key are ranked by lane, the first of them moves the wave's counter
+#pragma unroll
+    for (int q = 0; q < kPerThread; ++q) {
+        const size_t i = first + (size_t)q * 64 + lane;
+        const bool live = i < n;
+        const uint32_t k = live ? key[q] : 0xfffu;      // dead lanes only ever sit behind live ones (the tail of the batch)
+        unsigned long long peers = match_key(k) & __ballot(live);
+        const unsigned long long below = peers & ((1ull << lane) - 1ull);
+        const int rank = __popcll(below);
+        uint32_t before = 0;
+        if (live && rank == 0) before = atomicAdd(&s_wave[w][k >> 1], (uint32_t)__popcll(peers) << (16 * (k & 1u)));
+        const int leader = peers ? __ffsll((long long)peers) - 1 : 0;
+        before = __shfl(before, leader);
+        before = (before >> (16 * (k & 1u))) & 0xffffu;
+        if (live) {
+            const uint32_t at = s_off[k] + before + (uint32_t)rank;
+            slot_of[i] = at;
+            prob_of[at] = (uint32_t)i;
+        }
+    }
 }
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+inline unsigned tiles_for(size_t n) { return (unsigned)((n + kTileProblems - 1) / kTileProblems); }
 
 }  // namespace
 
-// scratch layout: keys in | keys out | index in | the sort's temporary storage
+// scratch layout: hist[tiles][4096] | total[4096] | keys[n] (16 bit)
 hipError_t schedule_scratch_bytes(size_t n, size_t *bytes)
 {
-    size_t temp = 0;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                                      (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 32, (hipStream_t)0);
-    *bytes = 3 * align256(n * sizeof(uint32_t)) + align256(temp);
-    return e;
+    *bytes = align256((size_t)tiles_for(n) * kKeys * sizeof(uint32_t)) + kKeys * sizeof(uint32_t) + align256(n * sizeof(uint16_t));
+    return hipSuccess;
 }
 
 hipError_t launch_schedule(const BatchView &b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride,
-                           void *d_scratch, size_t scratch_bytes, hipStream_t stream)
+                           bool write_records, void *d_scratch, size_t scratch_bytes, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
-    const size_t words = align256(b.n * sizeof(uint32_t));
-    if (scratch_bytes < 3 * words) return hipErrorInvalidValue;
-    uint32_t *keys_in = (uint32_t *)d_scratch;
-    uint32_t *keys_out = (uint32_t *)((char *)d_scratch + words);
-    uint32_t *index_in = (uint32_t *)((char *)d_scratch + 2 * words);
-    void *temp = (char *)d_scratch + 3 * words;
-    size_t temp_bytes = scratch_bytes - 3 * words;
-    const unsigned grid = (unsigned)((b.n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_schedule_keys, dim3(grid), dim3(kBlock), 0, stream, d_pos0, d_pos1, d_pos2, pstride, b.n, keys_in, index_in);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const uint32_t *)keys_in, keys_out, (const uint32_t *)index_in,
-                                                      b.prob_of, (int)b.n, 0, 32, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_invert, dim3(grid), dim3(kBlock), 0, stream, (const uint32_t *)b.prob_of, b.n, b.slot_of);
+    size_t need = 0;
+    (void)schedule_scratch_bytes(b.n, &need);
+    if (scratch_bytes < need || (write_records && !b.records)) return hipErrorInvalidValue;
+    const unsigned tiles = tiles_for(b.n);
+    uint32_t *hist = (uint32_t *)d_scratch;
+    uint32_t *total = (uint32_t *)((char *)d_scratch + align256((size_t)tiles * kKeys * sizeof(uint32_t)));
+    uint16_t *keys = (uint16_t *)(total + kKeys);
+    if (write_records)
+        hipLaunchKernelGGL((k_sched_count<true>), dim3(tiles), dim3(kThreads), 0, stream, d_pos0, d_pos1, d_pos2, pstride, b.n, hist, keys, b.records, b.counters);
+    else
+        hipLaunchKernelGGL((k_sched_count<false>), dim3(tiles), dim3(kThreads), 0, stream, d_pos0, d_pos1, d_pos2, pstride, b.n, hist, keys,
+                           (StartRecord *)nullptr, b.counters);
+    hipLaunchKernelGGL(k_sched_scan, dim3(kKeys / 16), dim3(kThreads), 0, stream, hist, tiles, total);
+    hipLaunchKernelGGL(k_sched_scatter, dim3(tiles), dim3(kThreads), 0, stream, (const uint16_t *)keys, b.n, (const uint32_t *)hist,
+                       (const uint32_t *)total, b.slot_of, b.prob_of);
     return hipGetLastError();
 }
 

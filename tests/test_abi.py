@@ -118,8 +118,24 @@ def test_bench_refuses_to_run_without_a_gpu():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no HIP device" in (r.stderr + r.stdout)
     assert "{" not in r.stdout          # no JSON line is ever printed from a CPU run
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "one process per GPU" in (r.stderr + r.stdout)
+    # `python bench.py --gpus 2` as typed (no RANK in the environment): the parent starts two ranks itself (torch.distributed.run)
+    # before it has touched torch or HIP; on a CPU box each rank then stops with "no HIP device" and the parent returns non-zero
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    out = r.stderr + r.stdout
+    assert r.returncode != 0
+    assert "starting 2 ranks" in out and "torch.distributed.run" in out
+    assert out.count("no HIP device") >= 2          # both children got as far as looking for their GPU
+    assert "{\"metric\"" not in r.stdout
+
+
+def test_abi_revision_of_header_library_and_binding_agree():
+    text = open(os.path.join(ROOT, "include", "rp_batch.h")).read()
+    rev = int(re.search(r"#define\s+RP_ABI_VERSION\s+(\d+)", text).group(1))
+    lib = capi.load_library()
+    assert lib.rp_abi_version() == rev == capi.ABI_VERSION
+    assert lib.rp_params_size() == ctypes.sizeof(capi.Params)
 
 
 def test_python_constants_mirror_the_header():

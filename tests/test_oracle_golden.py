@@ -43,6 +43,22 @@ def test_fixed_steps_match_golden(batch, oracle):
     assert _scale_err(aos[:, :3], batch["after50"][:, :3]) < 1e-10
 
 
+def test_multipliers_after_fifty_steps_are_pinned_only_where_they_are_determined(batch, oracle):
+    """After 50 fixed steps (35 of them in the reference's post-convergence regime) the oracle's own QR and the reference's
+    Eigen QR -- the fixture -- agree on the multipliers to rounding on the monotone and reference-like sets.  On the
+    non-monotone stress set the optimum has four active constraints for three variables, the multipliers have a null
+    direction, and the two CPU evaluations of the same algorithm drift apart along it (measured: 0.42 of the largest
+    multiplier at worst, median 8e-7): which is why the GPU test asserts no tolerance there."""
+    aos = batch["init"].copy()
+    oracle.batch_steps(3, aos, 50)
+    ref = batch["after50"][:, 3:11]
+    err = np.max(np.abs(aos[:, 3:11] - ref) / np.max(np.abs(ref), axis=1, keepdims=True), axis=1)
+    regular = batch["dist"] != 2
+    assert err[regular].max() < 1e-12
+    assert np.median(err[~regular]) < 1e-4 and err[~regular].max() > 1e-6      # drifted, but the same optimum
+    assert _scale_err(aos[:, :3], batch["after50"][:, :3]) < 1e-10
+
+
 def test_gated_solve_matches_golden(batch, oracle):
     aos = batch["init"].copy()
     iters, total = oracle.batch_solve_gated(3, aos, 1e-8, 200)
