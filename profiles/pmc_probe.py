@@ -21,6 +21,7 @@ for variant, dtype in ((rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F
     with rp.Batch(N, variant, dtype) as b:
         for _ in range(2):
             b.set_problems(p0, p1, p2)
+            b.restart()      # the feasible start written out (set_problems defers it to a fused solve)
             b.step(STEPS)
             b.sync()
 # the gated kernel with every lane doing the same work: 524,288 copies of the default problem (15 steps each, no idle
@@ -34,8 +35,10 @@ with rp.Batch(N // 2) as b:
 with rp.Batch(N) as b:
     for _ in range(2):
         b.set_problems(p0, p1, p2)
+        b.restart()      # the feasible start written out (set_problems defers it to a fused solve)
         b.solve(1e-8, 200, 0)
         b.sync()
     b.set_problems(p0, p1, p2)
+    b.restart()      # the feasible start written out (set_problems defers it to a fused solve)
     b.step(1)
     b.sync()

@@ -448,10 +448,16 @@ template <typename T> __device__ __forceinline__ T c_guard(T c, T c_floor) { ret
 // iterations; otherwise (or when a pivot is zero, or their product leaves the number range) the general
 // partial-pivot elimination runs.  The branch is per lane; a wave pays for both paths only while one of its
 // lanes is in the indefinite regime.
-template <typename T>
+// HALF: the caller passes the system scaled by D = diag(1/2, 1, 1) (a / 4, b / 2, c / 2, rv / 2: F3's assembly produces
+// them in that form) and gets 2 xv back; the pivot test compares against the unscaled off-diagonals, so it decides as it
+// would on the unscaled system.
+// (Measured and rejected in round 3: Cramer's rule instead of both paths -- 31 instructions, no branch, no compare-and-select
+// -- loses eps * w^2 where elimination loses eps * w while ONE constraint dominates K with weight w = lam / c (steps 2-3 of a
+// solve): 2.6e-7 off the oracle on 16 of 4,096 problems with non-zero end velocities, profiles/r3_tuning.md.)
+template <typename T, bool HALF = false>
 __device__ __forceinline__ void solve_arrow(T a, T b, T c, T d, T e, T rv, T r0, T r1, T &xv, T &x0, T &x1)
 {
-    const T alpha = T(0.6403882032022076);
+    const T alpha = HALF ? T(2.0 * 0.6403882032022076) : T(0.6403882032022076);
     const T de = d * e;
     if (abs_(d) >= alpha * abs_(b) && abs_(e) >= alpha * abs_(c) && de != T(0) && finite_(de)) {
         const T ide = rcp_(de);                              // one reciprocal for both pivots: 1/d = e/(d e)
@@ -475,9 +481,11 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
 {
     const T L = kp.limit;
     T htt[4], htv[4];
-    accel_hess(k, v, e, htt, htv);
-    T kvv = T(0), kv0 = T(0), kv1 = T(0), k00 = T(0), k11 = T(0);
-    T bv = T(0), b0 = T(-1), b1 = T(-1);
+    accel_hess(k, v, e, htt, htv);      // (F3 uses htt only: the mixed second derivatives are constants x 1/t^2, folded in below)
+    [[maybe_unused]] T kvv = T(0), kv0 = T(0), kv1 = T(0);
+    T k00 = T(0), k11 = T(0);
+    [[maybe_unused]] T bv = T(0);
+    T b0 = T(-1), b1 = T(-1);
 
     if constexpr (VARIANT == 3) {
         // 1/cm_j and 1/cp_j for the four accelerations from ONE reciprocal: with x_j = cm_j cp_j (= L^2 - a_j^2 > 0 inside
@@ -503,33 +511,39 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
                 icp[j] = cm[j] * ix[j];
             }
         }
+        // Assembly with the velocity gradients' constant coefficients folded in: d a_j / d vel1 = (-2, 4) / t0, (-4, 2) / t1
+        // (acc_gv), so S w_j gv_j^2 = 4 [q0 (w0 + 4 w1) + q1 (4 w2 + w3)] with q = 1/t^2, and likewise for the mixed entries
+        // and the right-hand side.  The common factors 4 and 2 are not multiplied out: the system is solved in the scaled
+        // unknown 2 dxv, i.e. for K' = D K D, rhs' = D rhs with D = diag(1/2, 1, 1) -- powers of two, so exact.
+        T w[4], dlt[4], qq[4], wgt[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const T lm = lam[2 * j], lp = lam[2 * j + 1];
-            const T w = fma_(lm, icm[j], lp * icp[j]);      // lm/cm + lp/cp
-            const T q = p * (icp[j] - icm[j]);              // rhs weight of grad a_j
-            const T d = lp - lm;
-            const T gv = acc_gv(e, j), gt = e.gt[j];
-            const T wgv = w * gv, wgt = w * gt;
-            kvv = fma_(-wgv, gv, kvv);
-            bv = fma_(gv, q, bv);
-            if (j < 2) {
-                kv0 = fma_(d, htv[j], fma_(-wgv, gt, kv0));
-                k00 = fma_(d, htt[j], fma_(-wgt, gt, k00));
-                b0 = fma_(gt, q, b0);
-            } else {
-                kv1 = fma_(d, htv[j], fma_(-wgv, gt, kv1));
-                k11 = fma_(d, htt[j], fma_(-wgt, gt, k11));
-                b1 = fma_(gt, q, b1);
-            }
+            w[j] = fma_(lm, icm[j], lp * icp[j]);      // lm/cm + lp/cp
+            dlt[j] = lp - lm;
+            qq[j] = icp[j] - icm[j];                   // x p: rhs weight of grad a_j
+            wgt[j] = w[j] * e.gt[j];
         }
-        solve_arrow<T>(kvv, kv0, kv1, k00, k11, bv, b0, b1, dxv, dx0, dx1);
+        const T r0 = e.r0, r1 = e.r1;
+        const T q0 = r0 * r0, q1 = r1 * r1;
+        const T kvv_q = fma_(-q1, fma_(T(4), w[2], w[3]), -(q0 * fma_(T(4), w[1], w[0])));                       // kvv / 4
+        const T kv0_h = fma_(q0, fma_(T(-2), dlt[1], dlt[0]), r0 * fma_(T(-2), wgt[1], wgt[0]));                  // kv0 / 2
+        const T kv1_h = fma_(q1, fma_(T(2), dlt[2], -dlt[3]), r1 * fma_(T(2), wgt[2], -wgt[3]));                  // kv1 / 2
+        k00 = fma_(dlt[0], htt[0], fma_(-wgt[0], e.gt[0], fma_(dlt[1], htt[1], -(wgt[1] * e.gt[1]))));
+        k11 = fma_(dlt[2], htt[2], fma_(-wgt[2], e.gt[2], fma_(dlt[3], htt[3], -(wgt[3] * e.gt[3]))));
+        const T bv_h = p * fma_(r0, fma_(T(2), qq[1], -qq[0]), r1 * fma_(T(-2), qq[2], qq[3]));                   // bv / 2
+        b0 = fma_(p, fma_(e.gt[0], qq[0], e.gt[1] * qq[1]), T(-1));
+        b1 = fma_(p, fma_(e.gt[2], qq[2], e.gt[3] * qq[3]), T(-1));
+        T xv2;                                                                                                    // 2 dxv
+        solve_arrow<T, true>(kvv_q, kv0_h, kv1_h, k00, k11, bv_h, b0, b1, xv2, dx0, dx1);
+        dxv = T(0.5) * xv2;
+        const T rx0 = r0 * xv2, rx1 = r1 * xv2;      // grad_v a_j . dxv = (-1, 2) rx0, (-2, 1) rx1
+        const T da[4] = {fma_(e.gt[0], dx0, -rx0), fma_(e.gt[1], dx0, rx0 + rx0), fma_(e.gt[2], dx1, -(rx1 + rx1)), fma_(e.gt[3], dx1, rx1)};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const T lm = lam[2 * j], lp = lam[2 * j + 1];
-            const T da = fma_(acc_gv(e, j), dxv, e.gt[j] * (j < 2 ? dx0 : dx1));
-            dl[2 * j] = fma_(icm[j], fma_(lm, da, -p), -lm);           // -lm + (lm da - p)/cm
-            dl[2 * j + 1] = fma_(-icp[j], fma_(lp, da, p), -lp);       // -lp - (lp da + p)/cp
+            dl[2 * j] = fma_(icm[j], fma_(lm, da[j], -p), -lm);           // -lm + (lm da - p)/cm
+            dl[2 * j + 1] = fma_(-icp[j], fma_(lp, da[j], p), -lp);       // -lp - (lp da + p)/cp
         }
     } else {
         T w[4], pc[4], gv[4], gt[4], icv[4];
@@ -749,10 +763,22 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     // behind that screen (a wave whose lanes all pass skips it).
     T s = kp.boundary;
     {
-        T tmin = lam[0] + dl[0];
+        // "some lam_i + dl_i is negative": the OR of the sums' sign bits instead of a running minimum (a -0 or a NaN with its
+        // sign bit set passes the screen too; the arg-min below then finds no ratio below 1 and leaves s = boundary, exactly as
+        // if it had been skipped)
+        bool any_negative;
+        if constexpr (sizeof(T) == 8) {
+            unsigned bits = 0u;
 #pragma unroll
-        for (int i = 1; i < NC; ++i) tmin = min_(tmin, lam[i] + dl[i]);
-        if (tmin < T(0)) {
+            for (int i = 0; i < NC; ++i) bits |= (unsigned)(__builtin_bit_cast(unsigned long long, lam[i] + dl[i]) >> 32);
+            any_negative = (int)bits < 0;
+        } else {
+            unsigned bits = 0u;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) bits |= __builtin_bit_cast(unsigned, lam[i] + dl[i]);
+            any_negative = (int)bits < 0;
+        }
+        if (any_negative) {
             T nb = T(1), eb = T(1);
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
@@ -808,9 +834,11 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     int it = 0;
     bool frozen = false;           // the trial point has become bitwise x (and stays so: s only shrinks)
     for (; it < kp.max_bt; ++it) {
-        tv = fma_(dxv, s, v);
-        tt0 = fma_(dx0, s, t0);
-        tt1 = fma_(dx1, s, t1);
+        if (!et_valid) {          // (et_valid: the feasibility loop ended on this very point with this very s -- nothing to redo)
+            tv = fma_(dxv, s, v);
+            tt0 = fma_(dx0, s, t0);
+            tt1 = fma_(dx1, s, t1);
+        }
         if (MEMO && tv == v && tt0 == t0 && tt1 == t1) { frozen = true; break; }
         if (!et_valid) accel_values(k, tv, tt0, tt1, et);
         accel_grads(k, tv, et);
@@ -932,7 +960,20 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     }
 
     // -- take the step (onedpath_ip.cpp:949-952) --
-    if (SUMS && accepted) {        // the accepted trial point and multipliers are the update, bit for bit
+    if constexpr (SUMS) {
+        // Gated kernels: the accepted trial point and multipliers ARE the update, bit for bit.  A loop that ran out of
+        // halvings (its last s was never evaluated) forms that last trial here, into the same registers, so that one set
+        // of values leaves the step whichever way it ended.
+        if (!accepted) {
+            tv = fma_(dxv, s, v);
+            tt0 = fma_(dx0, s, t0);
+            tt1 = fma_(dx1, s, t1);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) tl[i] = fma_(dl[i], s, lam[i]);
+            accel_values(k, tv, tt0, tt1, et);
+            accel_grads(k, tv, et);
+            residual_sums<T, VARIANT, false>(et, tl, dl, T(0), L, c.X, c.Q1, c.Q2);
+        }
         v = tv; t0 = tt0; t1 = tt1;
 #pragma unroll
         for (int i = 0; i < NC; ++i) lam[i] = tl[SUMS ? i : 0];
@@ -942,12 +983,10 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         t1 = fma_(dx1, s, t1);
 #pragma unroll
         for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
-    }
-
-    if (!accepted) {                                   // the loop ran out of halvings: its last s was never evaluated
-        accel_values(k, v, t0, t1, et);
-        if constexpr (!MEMO) accel_grads(k, v, et);
-        if constexpr (SUMS) residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2);
+        if (!accepted) {                               // the loop ran out of halvings: its last s was never evaluated
+            accel_values(k, v, t0, t1, et);
+            if constexpr (!MEMO) accel_grads(k, v, et);
+        }
     }
     c.r0 = et.r0; c.r1 = et.r1;
 #pragma unroll
