@@ -92,7 +92,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RP_BATCH_LIB") or LIB_PATH      # RP_BATCH_LIB: a tuning build of the same ABI (A/B runs)
     if path is None and not os.path.exists(p) and os.path.exists("/opt/rocm/bin/hipcc"):
         # a checkout without built artefacts (they are git-ignored): compile, never substitute
         import subprocess

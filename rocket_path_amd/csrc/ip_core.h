@@ -164,6 +164,7 @@ template <typename T, bool GT = false, bool RS = false> struct AccCarry {
     T a[4];
     T gt[GT ? 4 : 1];
     T X, Q1, Q2;      // unused (and not live) unless RS
+    T cm[RS ? 4 : 1], cp[RS ? 4 : 1];      // with RS, F3: the constraint values -a_j - L, a_j - L the sums were formed from -- the next direction starts from them
 };
 
 // d a_j / d vel1: dAdV1 of segment 0's ends (-2/t0, 4/t0), dAdV0 of segment 1's ends (-4/t1, 2/t1)
@@ -346,24 +347,30 @@ __device__ __forceinline__ T residual_norm(const Acc<T> &e, const T (&lam)[CMap<
 // comparison against r(x) can see -- it has to be beaten by a factor (1 - 0.01 s), not by rounding.)
 template <typename T, int VARIANT, bool TRIAL>
 __device__ __forceinline__ void residual_sums(const Acc<T> &e, const T (&lam)[CMap<VARIANT>::NC], const T (&dl)[CMap<VARIANT>::NC], T s, T L,
-                                              T &X, T &Q1, T &Q2)
+                                              T &X, T &Q1, T &Q2, T (&cm_out)[4], T (&cp_out)[4])
 {
     T rv = T(0), rt0 = T(1), rt1 = T(1), q1m = T(0), q1p = T(0), q2m = T(0), q2p = T(0);
     if constexpr (VARIANT == 3) {
+        T d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const T lm = TRIAL ? fma_(dl[2 * j], s, lam[2 * j]) : lam[2 * j];
             const T lp = TRIAL ? fma_(dl[2 * j + 1], s, lam[2 * j + 1]) : lam[2 * j + 1];
-            const T d = lp - lm;
-            rv = fma_(d, acc_gv(e, j), rv);
-            if (j < 2) rt0 = fma_(d, e.gt[j], rt0);
-            else       rt1 = fma_(d, e.gt[j], rt1);
-            const T tm = lm * (-e.a[j] - L), tp = lp * (e.a[j] - L);
+            d[j] = lp - lm;
+            if (j < 2) rt0 = fma_(d[j], e.gt[j], rt0);
+            else       rt1 = fma_(d[j], e.gt[j], rt1);
+            const T cm = -e.a[j] - L, cp = e.a[j] - L;
+            cm_out[j] = cm;
+            cp_out[j] = cp;
+            const T tm = lm * cm, tp = lp * cp;
             q1m += tm;
             q1p += tp;
             q2m = fma_(tm, tm, q2m);
             q2p = fma_(tp, tp, q2p);
         }
+        // S d_j grad_v a_j with the constant coefficients (-2, 4) / t0, (-4, 2) / t1 folded in (acc_gv): half of it, doubled exactly
+        const T rvh = fma_(e.r0, fma_(T(2), d[1], -d[0]), e.r1 * fma_(T(-2), d[2], d[3]));
+        rv = rvh + rvh;
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -475,9 +482,12 @@ __device__ __forceinline__ void solve_arrow(T a, T b, T c, T d, T e, T rv, T r0,
 
 // ---- the Newton direction (onedpath_ip.cpp:812-887, condensed) --------------------------
 // In: point (v; e = values + grads there), multipliers, perturbation p.  Out: dx, d lam.
-template <typename T, int VARIANT, class P>
+// HAVE_C: cm_in / cp_in hold -a_j - L and a_j - L of this very point (gated kernels carry them from the residual sums of the
+// accepted trial); otherwise they are formed here.
+template <typename T, int VARIANT, class P, bool HAVE_C = false>
 __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v, const T (&lam)[CMap<VARIANT>::NC],
-                                          const Acc<T> &e, T p, T &dxv, T &dx0, T &dx1, T (&dl)[CMap<VARIANT>::NC])
+                                          const Acc<T> &e, T p, T &dxv, T &dx0, T &dx1, T (&dl)[CMap<VARIANT>::NC],
+                                          const T *cm_in = nullptr, const T *cp_in = nullptr)
 {
     const T L = kp.limit;
     T htt[4], htv[4];
@@ -497,8 +507,8 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
             T cm[4], cp[4], x[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                cm[j] = -e.a[j] - L;
-                cp[j] = e.a[j] - L;
+                cm[j] = HAVE_C ? cm_in[j] : -e.a[j] - L;
+                cp[j] = HAVE_C ? cp_in[j] : e.a[j] - L;
                 x[j] = fma_(cm[j], cp[j], kp.x_floor);      // the c_guard shift, applied to the pair's product (see c_guard)
             }
             const T x01 = x[0] * x[1], x23 = x[2] * x[3];
@@ -679,9 +689,11 @@ struct HalvingDiag {
 // reference's line search.  Fewer steps to the same optimum (measured: 15.4 -> 12.7 mean on the benchmark distribution);
 // each step costs more, and results are NOT the reference's iterates -- opt-in, off by default.
 template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag>
-__device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
-                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c,
-                                            D &diag)
+__device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp, T gap,
+                                               const T v, const T t0, const T t1, const T (&lam)[CMap<VARIANT>::NC],
+                                               const AccCarry<T, !MEMO, !MEMO && MU == 0> &c,
+                                               T &nv, T &nt0, T &nt1, T (&nlam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &nc,
+                                               D &diag)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr bool SUMS = !MEMO && MU == 0;      // the residual in its carried form (residual_sums)
@@ -703,7 +715,12 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
             for (int j = 0; j < 4; ++j) e.gt[j] = c.gt[j];
         }
         if constexpr (MU == 0) {
-            direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
+#ifndef RP_NO_CARRIED_C      // tuning knob: 18 more VGPRs (146: three waves per SIMD instead of four) for 8 fewer instructions per step
+            if constexpr (SUMS && VARIANT == 3) direction<T, VARIANT, P, true>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, c.cm, c.cp);
+#else
+            if constexpr (false) {}
+#endif
+            else direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
             if constexpr (SUMS) r0n = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
             else r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);      // onedpath_ip.cpp:932
         } else {
@@ -731,15 +748,15 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
                     good = rq <= rx * (T(1) - kp.armijo * sq);
                 }
                 if (good) {                 // take it: the full step of the smaller centring parameter
-                    v = qv; t0 = q0; t1 = q1;
+                    nv = qv; nt0 = q0; nt1 = q1;
 #pragma unroll
-                    for (int i = 0; i < NC; ++i) lam[i] = fma_(tl[i], sq, lam[i]);
-                    c.r0 = eq.r0; c.r1 = eq.r1;
+                    for (int i = 0; i < NC; ++i) nlam[i] = fma_(tl[i], sq, lam[i]);
+                    nc.r0 = eq.r0; nc.r1 = eq.r1;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c.a[j] = eq.a[j];
+                    for (int j = 0; j < 4; ++j) nc.a[j] = eq.a[j];
                     if constexpr (!MEMO) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) c.gt[j] = eq.gt[j];
+                        for (int j = 0; j < 4; ++j) nc.gt[j] = eq.gt[j];
                     }
                     return;
                 }
@@ -847,8 +864,8 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
         if constexpr (SUMS) {
 #pragma unroll
             for (int i = 0; i < NC; ++i) tl[i] = fma_(dl[i], s, lam[i]);              // kept: the accepted trial IS the update
-            residual_sums<T, VARIANT, false>(et, tl, dl, T(0), L, c.X, c.Q1, c.Q2);   // overwritten by every trial: the accepted one stays
-            rn = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
+            residual_sums<T, VARIANT, false>(et, tl, dl, T(0), L, nc.X, nc.Q1, nc.Q2, nc.cm, nc.cp);   // overwritten by every trial: the accepted one stays
+            rn = residual_from_sums<T, NC>(nc.X, nc.Q1, nc.Q2, p);
         } else {
             rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
         }
@@ -972,29 +989,45 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
             for (int i = 0; i < NC; ++i) tl[i] = fma_(dl[i], s, lam[i]);
             accel_values(k, tv, tt0, tt1, et);
             accel_grads(k, tv, et);
-            residual_sums<T, VARIANT, false>(et, tl, dl, T(0), L, c.X, c.Q1, c.Q2);
+            residual_sums<T, VARIANT, false>(et, tl, dl, T(0), L, nc.X, nc.Q1, nc.Q2, nc.cm, nc.cp);
         }
-        v = tv; t0 = tt0; t1 = tt1;
+        nv = tv; nt0 = tt0; nt1 = tt1;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) lam[i] = tl[SUMS ? i : 0];
+        for (int i = 0; i < NC; ++i) nlam[i] = tl[SUMS ? i : 0];
     } else {
-        v = fma_(dxv, s, v);
-        t0 = fma_(dx0, s, t0);
-        t1 = fma_(dx1, s, t1);
+        nv = fma_(dxv, s, v);
+        nt0 = fma_(dx0, s, t0);
+        nt1 = fma_(dx1, s, t1);
 #pragma unroll
-        for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
+        for (int i = 0; i < NC; ++i) nlam[i] = fma_(dl[i], s, lam[i]);
         if (!accepted) {                               // the loop ran out of halvings: its last s was never evaluated
-            accel_values(k, v, t0, t1, et);
-            if constexpr (!MEMO) accel_grads(k, v, et);
+            accel_values(k, nv, nt0, nt1, et);
+            if constexpr (!MEMO) accel_grads(k, nv, et);
         }
     }
-    c.r0 = et.r0; c.r1 = et.r1;
+    nc.r0 = et.r0; nc.r1 = et.r1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c.a[j] = et.a[j];
+    for (int j = 0; j < 4; ++j) nc.a[j] = et.a[j];
     if constexpr (!MEMO) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c.gt[j] = et.gt[j];
+        for (int j = 0; j < 4; ++j) nc.gt[j] = et.gt[j];
     }
+}
+
+// the same in place
+template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag>
+__device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
+                                            T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c,
+                                            D &diag)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    T nv, nt0, nt1, nlam[NC];
+    AccCarry<T, !MEMO, !MEMO && MU == 0> nc;
+    newton_step_to<T, VARIANT, P, MEMO, AFFINE, MU, D>(k, kp, gap, v, t0, t1, lam, c, nv, nt0, nt1, nlam, nc, diag);
+    v = nv; t0 = nt0; t1 = nt1;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) lam[i] = nlam[i];
+    c = nc;
 }
 
 // the common call: no bookkeeping

@@ -117,7 +117,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
             accel_grads(pr, v, e0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) e.gt[j] = e0.gt[j];
-            if constexpr (Carry::has_sums) residual_sums<T, VARIANT, false>(e0, lam, lam, T(0), kp.limit, e.X, e.Q1, e.Q2);
+            if constexpr (Carry::has_sums) residual_sums<T, VARIANT, false>(e0, lam, lam, T(0), kp.limit, e.X, e.Q1, e.Q2, e.cm, e.cp);
         }
     };
     auto current_gap = [&]() -> T {
@@ -133,11 +133,12 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
 #ifdef RP_UNROLL2
 #pragma unroll 2
 #endif
+    const int budget = max_iter - it;      // gated steps this problem may still take: one per-lane counter per step (steps_here) serves both
     for (int s = 0; s < k; ++s) {
         const T gap = current_gap();
         if (GATED) {
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
-            if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; break; }
+            if (steps_here >= budget) { st |= RP_ST_MAXITER; done = true; break; }
             if (STALL && kp.stall_window > 0) {
                 if (gap < T(0.5) * best_gap) { best_gap = gap; since_best = 0; }
                 else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
@@ -150,9 +151,9 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
             for (int c = 0; c < CMap<VARIANT>::NC; ++c) lam[c] = (T)(S)lam[c];
             evaluate();                      // the carried evaluation belongs to the unrounded point
         }
-        ++it;
         ++steps_here;
     }
+    it += steps_here;
     if (GATED) {
         if (!done) {   // settle the status now so the host knows whether to launch again
             const T gap = current_gap();
