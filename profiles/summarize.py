@@ -119,7 +119,7 @@ for name, c in sq.items():
     elif name.startswith("k_steps_chunks<float, double, 4"):
         top["_flop_per_f4_step_f32state"] = f64
 # the gated kernel on identical problems: 15 steps per problem, no idle lanes
-GATED = "k_solve_chunks<double, double, 3, false, true, 0>"
+GATED = "k_solve_chunks<double, double, 3, false, true, 0, false>"
 if "SQ_INSTS_VALU_FMA_F64" in ident:
     ls = 15.0 * (N // 2)
     ident["flop_f64_per_lane_step"] = 64.0 * (2 * ident["SQ_INSTS_VALU_FMA_F64"] + ident["SQ_INSTS_VALU_MUL_F64"] + ident["SQ_INSTS_VALU_ADD_F64"]
