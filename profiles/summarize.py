@@ -73,8 +73,8 @@ alias("k_solve_chunks_f3_f64", "k_solve_chunks<double, double, 3, false, true",
 alias("k_newton_stream16_f3_f64", "k_newton_stream16<double, double, 3, true", "14x8 B read + 11x8 B written per problem = 117.4 + 92.3 MB")
 alias("k_newton_stream16_f4_f32", "k_newton_stream16<float, float, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
 alias("k_newton_stream16_f4_f32state", "k_newton_stream16<float, double, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
-alias("k_steps_regrouped_f4_f32", "k_steps_regrouped<float, float, 4", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per 50-step launch")
-alias("k_steps_regrouped_f4_f32state", "k_steps_regrouped<float, double, 4", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per 50-step launch")
+alias("k_steps_chunks_f4_f32", "k_steps_chunks<float, float, 4, true", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per launch")
+alias("k_steps_chunks_f4_f32state", "k_steps_chunks<float, double, 4, true", "(10x4) B read + 7x4 B written per problem = 41.9 + 29.4 MB per launch")
 alias("k_steps_chunks_f3_f64", "k_steps_chunks<double, double, 3, true", "14x8 B read + 11x8 B written per problem = 117.4 + 92.3 MB per launch")
 json.dump(out, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag), "w"), indent=1)
 

@@ -111,6 +111,16 @@ template <> __device__ __forceinline__ float rcp1_<float>(float x) { return rcp_
 // 1/den, or 0 for a zero denominator (rank-deficient pivot: that component of the step is 0)
 template <typename T> __device__ __forceinline__ T srcp_(T den) { return den != T(0) ? rcp_(den) : T(0); }
 
+// x of lane `src` (wave-uniform index) in every lane
+__device__ __forceinline__ int bcast_(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
+__device__ __forceinline__ float bcast_(float x, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); }
+__device__ __forceinline__ double bcast_(double x, int src)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // Solver constants in the compute type (rp_params, include/rp_batch.h).
 template <typename T> struct KParams {
     T limit;        // L
@@ -278,8 +288,11 @@ __device__ __forceinline__ bool all_satisfied(const A &e, T L)
 #pragma unroll
         for (int j = 0; j < 4; ++j) ok = ok && !(abs_(e.a[j]) > L);
     } else {
+        // (a^2 - L^2) / 2 > 0  <=>  fl(a^2) > fl(L^2): a floating-point difference has the sign of the comparison of its
+        // operands and halving keeps it (NaN: both false) -- one multiply and one compare per acceleration
+        const T l2 = L * L;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ok = ok && !(c_value<T, 4, A>(i, e, L) > T(0));
+        for (int i = 0; i < 4; ++i) ok = ok && !(e.a[i] * e.a[i] > l2);
     }
     return ok;
 }
@@ -688,7 +701,9 @@ struct HalvingDiag {
 // residual of its own p passes the reference's Armijo test) succeeds; otherwise the reference step is taken with the
 // reference's line search.  Fewer steps to the same optimum (measured: 15.4 -> 12.7 mean on the benchmark distribution);
 // each step costs more, and results are NOT the reference's iterates -- opt-in, off by default.
-template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag>
+// WAVE (ungated kernels whose lanes all take the same number of steps: every live lane of the wave is inside this function at
+// the same time): the residual loop's stragglers are served by the whole wave, see "wave-parallel line search" below.
+template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false>
 __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp, T gap,
                                                const T v, const T t0, const T t1, const T (&lam)[CMap<VARIANT>::NC],
                                                const AccCarry<T, !MEMO, !MEMO && MU == 0> &c,
@@ -850,6 +865,101 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
     T tl[SUMS ? NC : 1];           // gated kernels: the trial multipliers lam + s dl of the last evaluated trial
     int it = 0;
     bool frozen = false;           // the trial point has become bitwise x (and stays so: s only shrinks)
+    if constexpr (WAVE && !SUMS) {
+        // ---- wave-parallel line search ----
+        // F4 never converges (README.md:34): from step ~6 a few per cent of the problems walk ~50 residual halvings at every
+        // step, each with a full evaluation (the trial point still moves), while the other lanes of their wave have long
+        // accepted -- per 64-lane wave 847 residual trials over 50 steps where a lane needs 21
+        // (profiles/r2_f4_halving_probe.log).  Here the loop is wave-uniform, and once only a few lanes are still searching
+        // each of them is served by the WHOLE wave: its search state is broadcast and the live lane of rank q evaluates
+        // the trial the serial loop would make q halvings later (s 2^-q, exact for backtrack = 1/2) with the very same
+        // functions; a ballot gives the first trial at which the serial loop would stop halving moving points -- accepted,
+        // or the trial point has become x (then the frozen-regime loop below takes over, as in the serial form), or the
+        // halvings are used up.  The straggler jumps there (s, it) and re-evaluates that one trial in the common loop, so
+        // everything downstream is the serial code and every decision and every bit is the serial loop's
+        // (onedpath2_ip.cpp:791-833).
+#ifndef RP_WAVE_SERIAL_FIRST
+#define RP_WAVE_SERIAL_FIRST 1
+#endif
+#ifndef RP_WAVE_SERVE_AT_MOST
+#define RP_WAVE_SERVE_AT_MOST 16
+#endif
+        constexpr int kSerialFirst = RP_WAVE_SERIAL_FIRST, kServeAtMost = RP_WAVE_SERVE_AT_MOST;      // trials in lock step before anyone is served; stragglers worth serving one by one
+        const unsigned long long alive = __ballot(true);
+        const int lane_id = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int rank = __popcll(alive & ((1ull << lane_id) - 1ull)), nalive = __popcll(alive);
+        bool open = true;
+        for (int round = 0;; ++round) {
+            const unsigned long long om = __ballot(open);
+            if (om == 0ull) break;
+            if (round >= kSerialFirst && kp.backtrack == T(0.5) && __popcll(om) <= kServeAtMost) {
+                unsigned long long todo = om;
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    P bk = k;
+                    bk.dx0 = bcast_(k.dx0, src);
+                    bk.dx1 = bcast_(k.dx1, src);
+                    if constexpr (!P::zero_vel) { bk.v0 = bcast_(k.v0, src); bk.v2 = bcast_(k.v2, src); }
+                    const T bv = bcast_(v, src), bt0 = bcast_(t0, src), bt1 = bcast_(t1, src);
+                    const T bdv = bcast_(dxv, src), bd0 = bcast_(dx0, src), bd1 = bcast_(dx1, src);
+                    const T bs = bcast_(s, src), bp = bcast_(p, src), br0n = bcast_(r0n, src);
+                    const int bit = bcast_(it, src);
+                    T blam[NC], bdl[NC];
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) { blam[i] = bcast_(lam[i], src); bdl[i] = bcast_(dl[i], src); }
+                    const T sq = ldexp_(bs, -rank);                    // the step length of the serial loop's trial number bit + rank
+                    const bool beyond = bit + rank >= kp.max_bt;       // ... which it would not make
+                    const T qv = fma_(bdv, sq, bv), q0 = fma_(bd0, sq, bt0), q1 = fma_(bd1, sq, bt1);
+                    const bool still = (qv == bv && q0 == bt0 && q1 == bt1);
+                    Acc<T> eq;
+                    accel_values(bk, qv, q0, q1, eq);
+                    accel_grads(bk, qv, eq);
+                    const T rq = residual_norm<T, VARIANT, true>(eq, blam, bdl, sq, bp, L);
+                    const bool pass = rq <= br0n * (T(1) - kp.armijo * sq);
+                    const unsigned long long stop = __ballot(beyond || still || pass);
+                    // live lanes are ranked by lane number, so the lowest stopping lane holds the earliest stopping trial
+                    const int adv = stop ? __popcll(alive & ((1ull << (__ffsll((long long)stop) - 1)) - 1ull)) : nalive;
+                    if (lane_id == src) {
+                        s = ldexp_(s, -adv);
+                        it += adv;
+                        if constexpr (!std::is_same<D, NoDiag>::value)
+                            for (int q = 0; q < adv; ++q) diag.resid();
+                        et_valid = false;
+                    }
+                }
+            }
+            if (open) {      // one trial in lock step: the serial loop's body
+                if (!(it < kp.max_bt)) {
+                    open = false;                                  // halvings used up: the last s is never evaluated
+                } else {
+                    if (!et_valid) {
+                        tv = fma_(dxv, s, v);
+                        tt0 = fma_(dx0, s, t0);
+                        tt1 = fma_(dx1, s, t1);
+                    }
+                    if (MEMO && tv == v && tt0 == t0 && tt1 == t1) {
+                        frozen = true;
+                        open = false;
+                    } else {
+                        if (!et_valid) accel_values(k, tv, tt0, tt1, et);
+                        accel_grads(k, tv, et);
+                        diag.moving();
+                        const T rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
+                        et_valid = false;
+                        if (rn <= r0n * (T(1) - kp.armijo * s)) {
+                            accepted = true;
+                            open = false;
+                        } else {
+                            s *= kp.backtrack;
+                            diag.resid();
+                            ++it;
+                        }
+                    }
+                }
+            }
+        }
+    } else
     for (; it < kp.max_bt; ++it) {
         if (!et_valid) {          // (et_valid: the feasibility loop ended on this very point with this very s -- nothing to redo)
             tv = fma_(dxv, s, v);
@@ -1015,7 +1125,7 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
 }
 
 // the same in place
-template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag>
+template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false>
 __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
                                             T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c,
                                             D &diag)
@@ -1023,7 +1133,7 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
     constexpr int NC = CMap<VARIANT>::NC;
     T nv, nt0, nt1, nlam[NC];
     AccCarry<T, !MEMO, !MEMO && MU == 0> nc;
-    newton_step_to<T, VARIANT, P, MEMO, AFFINE, MU, D>(k, kp, gap, v, t0, t1, lam, c, nv, nt0, nt1, nlam, nc, diag);
+    newton_step_to<T, VARIANT, P, MEMO, AFFINE, MU, D, WAVE>(k, kp, gap, v, t0, t1, lam, c, nv, nt0, nt1, nlam, nc, diag);
     v = nv; t0 = nt0; t1 = nt1;
 #pragma unroll
     for (int i = 0; i < NC; ++i) lam[i] = nlam[i];

@@ -22,7 +22,8 @@
 //   k_newton_stream16  k <= 2 ungated steps, the HBM-streaming form: 16 B per lane (two doubles / four floats =
 //                      that many consecutive problems per lane), one global_load/store_dwordx4 per field
 //   k_newton_stream    the same with one problem per lane and a register prefetch: ragged remainders, mu_mode 1
-//   k_steps_regrouped  F4's long fixed-step runs (k >= 20) on large batches: tiles re-sorted by line-search cost every 4 steps
+//                      (F4: with the wave-parallel line search of newton_step_to -- a wave's stragglers in the residual loop
+//                      are served by the whole wave; round 2's LDS-regrouping kernel for F4 is gone, this is faster)
 // Problems are independent and nothing is re-read, so there is no L2 locality to arrange: consecutive blocks are dealt
 // round-robin over the 8 XCDs and touch disjoint cache lines.
 #include "ip_kernels.h"
@@ -88,8 +89,11 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 #ifndef RP_GATED_WAVES
 #define RP_GATED_WAVES 3     // tuning knob: 4 (128 VGPRs, 6 spilled) and 2 were measured, DESIGN.md tuning log
 #endif
+#ifndef RP_WAVE_LS
+#define RP_WAVE_LS 1      // wave-parallel line search in F4's fixed-step chunk kernel (0: the serial loop, for A/B runs)
+#endif
 #ifndef RP_TILED_WAVES
-#define RP_TILED_WAVES 3     // the large-batch kernels fit 168 VGPRs (gated solve: 136, fixed steps: 152; F4 regrouping: + 48 KiB of LDS per block)
+#define RP_TILED_WAVES 3     // the large-batch kernels fit 168 VGPRs (gated solve: 146, fixed steps: 152-158)
 #endif
 
 // The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
@@ -98,11 +102,14 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 // S = storage type of the batch.  When it differs from the compute type T (fp32 state, fp64 arithmetic) the state is
 // rounded to S after every step, so that a step is a function "S state -> S state" whatever the launch shape:
 // step(k) stays bit-identical to k x step(1).
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, class D = NoDiag>
+// WAVE (ungated launches only, whose live lanes all take the same k steps together): the residual loop's stragglers are served
+// by the whole wave (newton_step_to, "wave-parallel line search").
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open, D &diag)
 {
+    static_assert(!(WAVE && GATED), "lanes of a gated solve leave the loop at different steps");
     // gated kernels carry the time derivatives as well (newton_step's MEMO = !GATED) and, in the reference's mu mode, the
     // residual sums, from which the gap of the current point comes for free
     using Carry = AccCarry<T, GATED, GATED && MU == 0>;
@@ -144,7 +151,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                 else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
             }
         }
-        newton_step<T, VARIANT, P, !GATED, AFFINE, MU, D>(pr, kp, gap, v, t0, t1, lam, e, diag);      // gated solves never reach the regime the memoisation is for
+        newton_step<T, VARIANT, P, !GATED, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);      // gated solves never reach the regime the memoisation is for
         if constexpr (sizeof(S) != sizeof(T)) {
             v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
 #pragma unroll
@@ -173,13 +180,13 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
 }
 
 // the common call: no line-search bookkeeping
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0>
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, bool WAVE = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open)
 {
     NoDiag none;
-    run_lane<T, VARIANT, GATED, STALL, P, S, AFFINE, MU, NoDiag>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open, none);
+    run_lane<T, VARIANT, GATED, STALL, P, S, AFFINE, MU, NoDiag, WAVE>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open, none);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -341,7 +348,7 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     bool still_open = false;
     // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
     // its stalled problems), so all its fixed-step kernels use it and agree bit for bit; F3's would spill at three waves
-    run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+    run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, (VARIANT == 4), 0, RP_WAVE_LS && (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
     // the store addresses are formed only now: the barrier keeps the compiler from holding eleven of them in registers
     // across the steps (168 VGPRs and 4-10 spilled without it, 152 with it)
     size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -542,123 +549,6 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
 #else
     for (int q = 0; q < CB; ++q) *reinterpret_cast<V *>(base + (size_t)q * stride + j) = f[q];
 #endif
-}
-
-// ---------------------------------------------------------------------------------------
-// Tiles of the F4 regrouping kernel below: 512 consecutive positions per 256-thread block, staged in LDS.
-#ifndef RP_TILE
-#define RP_TILE 512      // problems per tile; the block has RP_TILE / 2 threads (each wave two 64-problem chunks)
-#endif
-constexpr int kTile = RP_TILE;
-constexpr int kTileThreads = kTile / 2;
-constexpr size_t kTiledMin = 262144;      // below this many problems the 512-problem tiles of k_steps_regrouped cannot fill the chip
-constexpr int kBuckets = 64;
-
-// ---------------------------------------------------------------------------------------
-// Fixed-step runs of F4: k ungated steps per problem with the tile's problems REGROUPED every few steps by what their line
-// searches cost.  F4 is chaotic and never converges (README.md:34): from step ~20 on a few per cent of the problems sit in
-// a ~50-halving residual loop at every step -- and stay there (measured: a lane with more than 20 residual halvings at one
-// step has them at the next step too, with probability 1.00) -- while the others take a handful of feasibility halvings.
-// In any fixed assignment every wave soon holds such a lane and pays for it at every step (per 64-lane wave 113 k line-search
-// instructions over 50 steps against 13 k per lane, profiles/r2_f4_persistence_probe.log).  Here the block sorts its 512
-// problems by the cost of their last few steps (counting sort in LDS, most expensive first) and its four waves pull
-// 64-problem chunks from a queue: the expensive problems end up together in one chunk, one wave works through it while the
-// other three drain the cheap chunks.  State stays in LDS between regroupings; which lane steps a problem changes nothing in
-// its result (bit-identical to the other kernels: tests).
-template <typename S, typename T, int VARIANT, bool ZV>
-__global__ void __launch_bounds__(kTileThreads, RP_TILED_WAVES)
-k_steps_regrouped(S *__restrict__ base, size_t stride, size_t n, int k, int every, KParams<T> kp)
-{
-    constexpr int NC = CMap<VARIANT>::NC;
-    constexpr int CB = 3 + NC;
-    __shared__ S sm[CB][kTile];
-    __shared__ T s_dx[2][kTile];                         // pos1 - pos0, pos2 - pos1 in the arithmetic type
-    __shared__ T s_ve[ZV ? 1 : 2][ZV ? 1 : kTile];       // end velocities (general instantiation only)
-    __shared__ uint16_t s_perm[kTile];                   // queue position -> problem of the tile
-    __shared__ uint8_t s_key[kTile];                     // cost bucket of the last `every` steps, per problem
-    __shared__ unsigned s_hist[kBuckets], s_start[kBuckets], s_fill[kBuckets];
-    __shared__ int s_next;
-
-    const int tid = threadIdx.x;
-    const size_t first = (size_t)blockIdx.x * kTile;
-    const int count = (n - first < (size_t)kTile) ? (int)(n - first) : kTile;
-#pragma unroll
-    for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kTileThreads) sm[f][j] = ld_once(base + (size_t)f * stride + first + j);
-    for (int j = tid; j < count; j += kTileThreads) {
-        const S *g = base + first + j;
-        const T q0 = (T)g[(size_t)(CB + 0) * stride], q1 = (T)g[(size_t)(CB + 2) * stride], q2 = (T)g[(size_t)(CB + 3) * stride];
-        s_dx[0][j] = q1 - q0;
-        s_dx[1][j] = q2 - q1;
-        if constexpr (!ZV) {
-            s_ve[0][j] = (T)g[(size_t)(CB + 1) * stride];
-            s_ve[1][j] = (T)g[(size_t)(CB + 4) * stride];
-        }
-        s_perm[j] = (uint16_t)j;
-    }
-    __syncthreads();
-
-    const int lane = tid & 63;
-    for (int done = 0; done < k; done += every) {
-        const int now = (k - done < every) ? (k - done) : every;
-        if (tid == 0) s_next = 0;
-        __syncthreads();
-        for (;;) {      // every wave reaches the exit: the queue only grows, and chunk * 64 >= count ends it
-            int chunk = 0;
-            if (lane == 0) chunk = atomicAdd(&s_next, 1);
-            chunk = __builtin_amdgcn_readfirstlane(chunk);
-            if (chunk * 64 >= count) break;
-            const int slot = chunk * 64 + lane;
-            if (slot < count) {
-                const int j = s_perm[slot];
-                T v = (T)sm[0][j], t0 = (T)sm[1][j], t1 = (T)sm[2][j];
-                T lam[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) lam[c] = (T)sm[3 + c][j];
-                Prob<T, ZV> pr;
-                pr.dx0 = s_dx[0][j];
-                pr.dx1 = s_dx[1][j];
-                if constexpr (!ZV) {
-                    pr.v0 = s_ve[0][j];
-                    pr.v2 = s_ve[1][j];
-                }
-                int it = 0, steps_here = 0;
-                uint32_t st = 0;
-                bool still_open = false;
-                HalvingDiag diag;
-                run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, true, 0, HalvingDiag>(pr, kp, now, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, diag);      // AFFINE as in the streaming kernels: same bits
-                sm[0][j] = (S)v;
-                sm[1][j] = (S)t0;
-                sm[2][j] = (S)t1;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) sm[3 + c][j] = (S)lam[c];
-                // a residual trial costs about three feasibility trials; 8 units per bucket, expensive first
-                const unsigned cost = (3u * diag.nr + diag.nf) / (unsigned)now;
-                const unsigned b = cost >> 3;
-                s_key[j] = (uint8_t)(kBuckets - 1 - (b < (unsigned)kBuckets ? b : (unsigned)kBuckets - 1));
-            }
-        }
-        __syncthreads();
-        if (done + every < k) {      // counting sort of the tile's problems by bucket (LDS atomics)
-            if (tid < kBuckets) { s_hist[tid] = 0; s_fill[tid] = 0; }
-            __syncthreads();
-            for (int j = tid; j < count; j += kTileThreads) atomicAdd(&s_hist[s_key[j]], 1u);
-            __syncthreads();
-            if (tid == 0) {
-                unsigned acc = 0;
-                for (int b = 0; b < kBuckets; ++b) { s_start[b] = acc; acc += s_hist[b]; }
-            }
-            __syncthreads();
-            for (int j = tid; j < count; j += kTileThreads) {
-                const unsigned pos = s_start[s_key[j]] + atomicAdd(&s_fill[s_key[j]], 1u);
-                s_perm[pos] = (uint16_t)j;
-            }
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int f = 0; f < CB; ++f)
-        for (int j = tid; j < count; j += kTileThreads) st_once(base + (size_t)f * stride + first + j, sm[f][j]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1067,14 +957,6 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     // kernel down to 4,096 problems, 65,536 x 50 steps included (0.333 against 0.363 ms).
     static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override: forces the streaming kernel
     if (k >= 3 && !grid_env) {
-        const unsigned tiles = (unsigned)((b.n + kTile - 1) / kTile);
-        static const bool no_regroup = getenv("RP_NO_REGROUP") != nullptr;      // A/B switch for tuning
-        static const int every = getenv("RP_REGROUP_EVERY") ? atoi(getenv("RP_REGROUP_EVERY")) : 4;      // tuning
-        if (b.variant == 4 && k >= 20 && b.n >= kTiledMin && !no_regroup && every >= 1) {      // F4's long fixed-step runs on large batches: see k_steps_regrouped
-            RP_DISPATCH_Z(b, if constexpr (V == 4) hipLaunchKernelGGL((k_steps_regrouped<S, T, 4, Z>), dim3(tiles), dim3(kTileThreads), 0, stream,
-                                                                      (S *)b.base, b.stride, b.n, k, every, make_kparams<T>(hp, 4)));
-            return hipGetLastError();
-        }
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V, Z>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
                                              (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
         return hipGetLastError();

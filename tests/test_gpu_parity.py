@@ -877,22 +877,28 @@ def test_halving_counts_on_the_other_distributions_and_f4(oracle, variant, dist,
 
 
 @pytest.mark.parametrize("dtype", [rp.DTYPE_F64, rp.DTYPE_F32_STATE, rp.DTYPE_F32])
-def test_f4_regrouped_fixed_steps_equal_single_steps_bitwise(dtype):
-    # F4's long fixed-step runs on large batches go through k_steps_regrouped (problems re-sorted by line-search cost every four
-    # steps, chunks pulled from a queue): which lane steps a problem, and when, must not change a bit of its result
+def test_f4_wave_parallel_line_search_equals_single_steps_bitwise(dtype):
+    # F4's fused fixed-step launches serve the stragglers of the residual loop with the whole wave (newton_step_to, WAVE:
+    # the straggler's state is broadcast, every live lane evaluates one of its next 64 step lengths, a ballot finds the first
+    # trial the serial loop would stop at).  The single-step launches run the serial loop.  Which lane evaluated a trial must
+    # not change a bit of any result -- through the regime where F4's problems walk ~50 residual halvings per step (from
+    # step ~6 on for a growing share of them: this is what the service is for), with a ragged last wave (n % 64 = 13), and
+    # the halving counts must be the serial loop's.
     n = 512 * 512 + 77
     p0, p1, p2 = rp.problems.generate(2026, 0, n, rp.problems.DIST_MONOTONE)
     with rp.Batch(n, rp.VARIANT_F4, dtype) as a, rp.Batch(n, rp.VARIANT_F4, dtype) as b:
         a.set_problems(p0, p1, p2)
         b.set_problems(p0, p1, p2)
-        a.step(14)                       # k_steps_chunks (k < 20)
+        a.step(14)                       # k_steps_chunks with the wave-parallel search
         for _ in range(14):
-            b.step(1)                    # streaming kernel
+            b.step(1)                    # streaming kernel, serial search
         sa, sb = a.get_state(), b.get_state()
         assert np.all(np.isfinite(sa))
         assert np.array_equal(sa, sb)
-        a.step(22)                       # regrouped kernel: 4 + 4 + 4 + 4 + 4 + 2 steps
-        for _ in range(22):
+        a.step(22)
+        for _ in range(21):
             b.step(1)
+        nf, nr = b.step_counted(1)       # the diagnostic kernel: serial too; by now the long residual loops are there
         assert np.array_equal(a.get_state(), b.get_state())
         assert np.all(a.get_iters()[0] == 36)
+        assert (nr > 20).sum() > 30, (nr > 20).sum()      # ... so the service did run on the other side (fp64: ~1 % of the problems, fp32: a few dozen)
