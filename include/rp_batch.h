@@ -151,13 +151,11 @@ RP_API int rp_batch_nudge(rp_batch *b, int var_index, double delta);
 /* k times onKey('n') = moveInteriorPoint (onedpath_ip.cpp:810-953 / onedpath2_ip.cpp:698-841)
  * on every problem, ungated, fused into one launch (state stays in registers between steps). */
 RP_API int rp_batch_step(rp_batch *b, int k);
-/* Diagnostic twin of rp_batch_step: the same k steps, returning per problem how often the feasibility loop
- * (onedpath_ip.cpp:927) and the residual loop (:944) halved the step over those k steps.  For decision-level comparisons with
- * the reference; one problem per lane, synchronous, not a fast path.  Same arithmetic as rp_batch_step; the point (v, t0, t1) it
- * leaves is bit-identical to rp_batch_step's for every k and variant.  The multipliers are bit-identical too except for F3 once
- * the point has stopped moving (the reference's post-convergence regime, step ~20 on): there this kernel and the k <= 2
- * launches evaluate the residual loop on affine pieces, the k >= 3 launches directly, and the multipliers agree to 1e-12
- * relative, not bit for bit (tests/test_gpu_parity.py, test_launch_shapes_agree_through_the_post_convergence_regime). */
+/* Diagnostic twin of rp_batch_step: the same k steps (same arithmetic: results are bit-identical to rp_batch_step's, state and
+ * multipliers, for every k, variant and number mode -- every fixed-step kernel of a variant evaluates the reference's
+ * post-convergence residual loop in the same form), returning per problem how often the feasibility loop
+ * (onedpath_ip.cpp:927) and the residual loop (:944) halved the step over those k steps.  For decision-level comparisons with the
+ * reference; one problem per lane, synchronous, not a fast path. */
 RP_API int rp_batch_step_counted(rp_batch *b, int k, uint32_t *feas_halvings, uint32_t *resid_halvings);
 /* Gated solve, the convention of SURVEY.md appendix A.5 per problem:
  *     for (it = 0; it < max_iter; ++it) { if (gap < gap_tol) break; step; }

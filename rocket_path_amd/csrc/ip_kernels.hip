@@ -18,8 +18,8 @@
 //   k_solve_chunks     the gated solve (the benchmark's kernel): one 64-problem chunk of the scheduled order per
 //                      single-wave block, state in registers from its first load to its last store, no LDS, longest
 //                      chunks dispatched first
-//   k_steps_chunks     k >= 3 ungated steps: the same shape, fixed step count
-//   k_newton_stream16  k <= 2 ungated steps, the HBM-streaming form: 16 B per lane (two doubles / four floats =
+//   k_steps_chunks     k >= 2 ungated steps: the same shape, fixed step count
+//   k_newton_stream16  k = 1 (one launch per Newton step), the HBM-streaming form: 16 B per lane (two doubles / four floats =
 //                      that many consecutive problems per lane), one global_load/store_dwordx4 per field
 //   k_newton_stream    the same with one problem per lane and a register prefetch: ragged remainders, mu_mode 1
 //                      (F4: with the wave-parallel line search of newton_step_to -- a wave's stragglers in the residual loop
@@ -89,6 +89,12 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 #ifndef RP_GATED_WAVES
 #define RP_GATED_WAVES 3     // tuning knob: 4 (128 VGPRs, 6 spilled) and 2 were measured, DESIGN.md tuning log
 #endif
+// Which residual-loop form the fixed-step kernels use once the trial point has become x (newton_step's AFFINE): every kernel of
+// a variant uses the same one, so that all launch shapes agree bit for bit.  F4 reaches that regime within a dozen steps
+// (its stalled problems) and has the registers: affine pieces.  F3 reaches it only after convergence (step ~20 of a fixed-step
+// run); the 44 registers of the pieces would cost every F3 fixed-step kernel a wave per SIMD (k_newton_stream16: 200 -> 3 waves
+// instead of 2), which the HBM-streaming k = 1 launch of a live solve needs more than a converged batch needs cheap halvings.
+template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
 #ifndef RP_WAVE_LS
 #define RP_WAVE_LS 1      // wave-parallel line search in F4's fixed-step chunk kernel (0: the serial loop, for A/B runs)
 #endif
@@ -315,7 +321,7 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
 }
 
 // ---------------------------------------------------------------------------------------
-// k >= 3 ungated steps per problem on large batches: arithmetic-bound like the gated solve, and the same shape -- one
+// k >= 2 ungated steps per problem: arithmetic-bound like the gated solve, and the same shape -- one
 // single-wave block per 64 consecutive positions, state loaded straight into registers, k steps, stored; no LDS.  (Until
 // late in round 2 this was a 512-problem tile staged in LDS, the only form that fitted three waves per SIMD: the compiler
 // kept the eleven store addresses in registers across the steps.  Forming them after the steps, below, saved 16 VGPRs and
@@ -348,7 +354,7 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     bool still_open = false;
     // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
     // its stalled problems), so all its fixed-step kernels use it and agree bit for bit; F3's would spill at three waves
-    run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, (VARIANT == 4), 0, RP_WAVE_LS && (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+    run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>, 0, RP_WAVE_LS && (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
     // the store addresses are formed only now: the barrier keeps the compiler from holding eleven of them in registers
     // across the steps (168 VGPRs and 4-10 spilled without it, 152 with it)
     size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -409,7 +415,7 @@ k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, true, MU>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>, MU>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
         S *f = base + i;
         f[0 * stride] = (S)v;
         f[1 * stride] = (S)t0;
@@ -457,7 +463,7 @@ k_newton_counted(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T
     HalvingDiag diag;
     for (int s = 0; s < k; ++s) {
         const T gap = duality_gap<T, VARIANT, AccCarry<T, false, false>>(e, lam, kp.limit);
-        newton_step<T, VARIANT, Prob<T, false>, true, true, 0, HalvingDiag>(pr, kp, gap, v, t0, t1, lam, e, diag);
+        newton_step<T, VARIANT, Prob<T, false>, true, kAffine<VARIANT>, 0, HalvingDiag>(pr, kp, gap, v, t0, t1, lam, e, diag);
         if constexpr (sizeof(S) != sizeof(T)) {
             v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
 #pragma unroll
@@ -534,7 +540,7 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, true>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
         f[0][c] = (S)v;
         f[1][c] = (S)t0;
         f[2][c] = (S)t1;
@@ -949,19 +955,18 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
                                                  (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
         return hipGetLastError();
     }
-    // resident set: 256 CUs x 2 blocks (2 waves per SIMD); larger batches are walked with that stride
-    // k <= 2 is memory-bound: the streaming kernel, grid = the resident set (256 CUs x 2 blocks) so that each lane
-    // walks 8 problems at 1 Mi and its register prefetch hides the HBM latency.  Larger k is arithmetic-bound: there
-    // the second register set of the prefetch only costs occupancy, so k >= 3 runs k_steps_chunks (one problem per lane,
-    // no prefetch, 152 VGPRs: 3 waves per SIMD) at every batch size -- measured equal or faster than the prefetching
-    // kernel down to 4,096 problems, 65,536 x 50 steps included (0.333 against 0.363 ms).
+    // k = 1 is memory-bound (200 B per problem cross HBM for one step's arithmetic): the 16-byte streaming kernel.  From k = 2 on
+    // the arithmetic dominates and k_steps_chunks runs (one problem per lane, no second register set, 152-158 VGPRs: 3 waves per
+    // SIMD) at every batch size -- measured at 1 Mi problems: k = 1 5.3 TB/s (stream16) against 5.1, k = 2 0.042 ms (chunks)
+    // against 0.047 (profiles/r3_k1_ab_probe.log); round 2 had drawn the line at k = 3 against the LDS-tiled form of the day.
     static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override: forces the streaming kernel
-    if (k >= 3 && !grid_env) {
+    static const int chunks_from = getenv("RP_CHUNKS_FROM_K") ? atoi(getenv("RP_CHUNKS_FROM_K")) : 2;      // tuning override: smallest k that takes k_steps_chunks
+    if (k >= chunks_from && k >= 1 && !grid_env) {
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V, Z>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
                                              (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
         return hipGetLastError();
     }
-    // k <= 2: memory-bound.  Full blocks of 256 lanes x 16 B go through k_newton_stream16; the ragged remainder (and,
+    // k = 1: memory-bound.  Full blocks of 256 lanes x 16 B go through k_newton_stream16; the ragged remainder (and,
     // under RP_STREAM_SCALAR=1, everything: the A/B switch of the tuning log) through the 8-byte prefetching kernel.
     static const bool scalar_only = getenv("RP_STREAM_SCALAR") != nullptr;
     const size_t per_block = (size_t)kBlock * (b.dtype == 1 ? 4 : 2);      // problems per lane: Vec16<S, T>::PER
