@@ -33,7 +33,10 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert {e for e in exported if e.startswith("rp_")} == set(_declared_symbols())
-    assert not [e for e in exported if "newton" in e or "oracle" in e or "orc_" in e]
+    assert not [e for e in exported if "newton" in e or "oracle" in e or "orc_" in e or e.startswith("ref")]
+    # ... and the product library links neither the oracle nor anything built from the reference
+    needed = subprocess.run(["readelf", "-d", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "ip_oracle" not in needed and "ref_hotpath" not in needed and "eigen_qr_ref" not in needed
 
 
 def test_version_status_strings_and_defaults():
