@@ -124,6 +124,27 @@ def cpu_baseline(sample_n):
             out["with_reference_eigen_qr"] = {"value": total2 / dt2, "single_core_value": total3 / dt3, "cores": threads}
     except Exception as exc:      # the baseline must never take the benchmark down
         out["with_reference_eigen_qr"] = {"error": str(exc)}
+    # the reference's own functions (oracle/_ref/libref_hotpath.so: onedpath_ip.cpp's hot path compiled in the build
+    # container from the reference tree), one thread, a small slice: every moveInteriorPoint call formats its 11 x 11
+    # matrix into printf (to /dev/null here), which is most of its time -- reported for completeness, not as the baseline
+    try:
+        from oracle_api import Reference, have_ref_hotpath
+        if have_ref_hotpath():
+            ref = Reference()
+            n2 = max(1, sample_n // 256)
+            aos4 = orc.batch_init_feasible(3, p0[:n2], p1[:n2], p2[:n2])
+            t0 = time.perf_counter()
+            _, total4 = ref.batch_solve_gated(3, aos4, GAP_TOL, MAX_ITER)
+            dt4 = time.perf_counter() - t0
+            check = orc.batch_init_feasible(3, p0[:n2], p1[:n2], p2[:n2])
+            _, total5 = orc.batch_solve_gated(3, check, GAP_TOL, MAX_ITER, threads=1)
+            out["reference_library_with_its_prints"] = {
+                "value": total4 / dt4, "cores": 1, "kind": "reference", "steps": int(total4),
+                "same_steps_as_the_port": bool(total4 == total5),
+                "note": "the reference's moveInteriorPoint prints its KKT matrix at every step (onedpath_ip.cpp:865-899); "
+                        "SURVEY section 6 measured 0.45-0.47 M steps/s per core with the prints compiled out"}
+    except Exception as exc:
+        out["reference_library_with_its_prints"] = {"error": str(exc)}
     return out
 
 

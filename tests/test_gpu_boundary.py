@@ -181,6 +181,45 @@ def test_restart_is_the_feasible_start_of_the_positions_in_the_batch():
         assert np.array_equal(a.get_state(), b.get_state()) and np.array_equal(a.get_iters()[0], b.get_iters()[0])
 
 
+@pytest.mark.parametrize("variant,dtype", [(rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F3, rp.DTYPE_F32_STATE), (rp.VARIANT_F4, rp.DTYPE_F64),
+                                           (rp.VARIANT_F4, rp.DTYPE_F32_STATE), (rp.VARIANT_F4, rp.DTYPE_F32)])
+def test_a_fresh_batch_solves_from_a_start_it_never_wrote_out(variant, dtype):
+    # set_problems leaves the feasible start to the fused solve, which forms it in registers (k_solve_chunks<START>); any
+    # other consumer has it written out first (k_start_from_records).  Both must be the same start and give the same solve,
+    # bit for bit -- in every number mode, with a ragged last chunk, after a batch was used for something else before.
+    n = 3 * 4096 + 37
+    p0, p1, p2 = rp.problems.generate(808, 0, n, rp.problems.DIST_MONOTONE)
+    tol, cap = (1e-8, 200) if variant == rp.VARIANT_F3 else (1e-3, 12)      # F4 does not converge: the cap ends it
+    with rp.Batch(n, variant, dtype) as a, rp.Batch(n, variant, dtype) as b, rp.Batch(n, variant, dtype) as c:
+        a.set_problems(p0, p1, p2)
+        a.solve(tol, cap, 0)                       # the fused solve of a fresh batch
+        b.set_problems(p0, p1, p2)
+        start = b.get_state()                      # written out
+        assert np.all(start[:, 0] == 0) and np.all(start[:, 3:-5] == 1) and np.all(start[:, -4] == 0) and np.all(start[:, -1] == 0)
+        b.solve(tol, cap, 0)
+        c.init_default()                           # a batch with history: other state, other order, non-zero end velocities
+        c.step(3)
+        c.nudge(start.shape[1] - 4, 0.25)
+        c.set_problems(p0, p1, p2)
+        c.solve(tol, cap, 0)
+        sa, sb, sc = a.get_state(), b.get_state(), c.get_state()
+        assert np.array_equal(sa, sb) and np.array_equal(sa, sc)
+        ia, ib, ic = a.get_iters(), b.get_iters(), c.get_iters()
+        assert np.array_equal(ia[0], ib[0]) and np.array_equal(ia[1], ib[1]) and np.array_equal(ia[0], ic[0]) and np.array_equal(ia[1], ic[1])
+        assert a.reduce() == b.reduce() == c.reduce()
+        assert np.array_equal(sa[:, -5], start[:, -5]) and np.array_equal(sa[:, -3:-1], start[:, -3:-1])      # the positions reached the constant fields
+        # a solve that cannot start from registers (stall detector on) takes the written-out start: same result while nothing stalls
+        if variant == rp.VARIANT_F3:
+            c.set_params(stall_window=50)
+            c.set_problems(p0, p1, p2)
+            c.solve(tol, cap, 0)
+            assert np.array_equal(c.get_state(), sa)
+        # restart of a batch that is still "fresh" is that same start
+        b.set_problems(p0, p1, p2)
+        b.restart()
+        assert np.array_equal(b.get_state(), start) and not b.get_iters()[0].any()
+
+
 def test_single_process_sharded_bench_prints_the_bench_keys():
     # the C++ multi-GPU host measurable the moment a multi-GPU node exists; here on the one device
     import json
