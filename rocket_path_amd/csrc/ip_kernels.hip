@@ -998,6 +998,12 @@ hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k,
 static hipError_t launch_chunks(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, bool from_start, hipStream_t stream)
 {
     const dim3 grid((unsigned)((b.n + 63) / 64)), block(64);
+    static const unsigned lds_pad = getenv("RP_GATED_LDS_PAD") ? (unsigned)atoi(getenv("RP_GATED_LDS_PAD")) : 0u;      // tuning: dynamic LDS per block, to cap the waves per SIMD
+    if (lds_pad) {
+        hipLaunchKernelGGL((k_solve_chunks<double, double, 3, false, true>), grid, block, lds_pad, stream, (double *)b.base, b.stride, b.n, k,
+                           make_kparams<double>(hp, 3), gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit);
+        return hipGetLastError();
+    }
     if (from_start) {      // reference mode, no stall detector, zero end velocities: rp_batch.cpp only asks for this form then
         if (hp.mu_mode != 0 || hp.stall_window > 0 || !b.zero_end_vel || !b.records) return hipErrorInvalidValue;
         RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, false, true, 0, true>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,

@@ -105,18 +105,36 @@ k_sched_scan(uint32_t *__restrict__ hist, unsigned ntiles, uint32_t *__restrict_
     const unsigned g = threadIdx.x >> 4;
     const unsigned per = (ntiles + 15) / 16;
     const unsigned r0 = g * per, r1 = (r0 + per < ntiles) ? r0 + per : ntiles;
+    constexpr unsigned kInRegs = 16;      // up to 256 tiles (1 Mi problems) a thread's rows stay in registers between the two sweeps
+    uint32_t held[kInRegs];
     uint32_t sum = 0;
-    for (unsigned r = r0; r < r1; ++r) sum += hist[(size_t)r * kKeys + key];
+    if (per <= kInRegs) {
+#pragma unroll
+        for (unsigned q = 0; q < kInRegs; ++q) {
+            held[q] = (r0 + q < r1) ? hist[(size_t)(r0 + q) * kKeys + key] : 0u;
+            sum += held[q];
+        }
+    } else {
+        for (unsigned r = r0; r < r1; ++r) sum += hist[(size_t)r * kKeys + key];
+    }
     s_seg[g][threadIdx.x & 15] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (unsigned q = 0; q < g; ++q) run += s_seg[q][threadIdx.x & 15];
     if (g == 15) total[key] = run + sum;
-    for (unsigned r = r0; r < r1; ++r) {
-        const size_t at = (size_t)r * kKeys + key;
-        const uint32_t v = hist[at];
-        hist[at] = run;
-        run += v;
+    if (per <= kInRegs) {
+#pragma unroll
+        for (unsigned q = 0; q < kInRegs; ++q) {
+            if (r0 + q < r1) hist[(size_t)(r0 + q) * kKeys + key] = run;
+            run += held[q];
+        }
+    } else {
+        for (unsigned r = r0; r < r1; ++r) {
+            const size_t at = (size_t)r * kKeys + key;
+            const uint32_t v = hist[at];
+            hist[at] = run;
+            run += v;
+        }
     }
 }
 
@@ -163,10 +181,17 @@ k_sched_scatter(const uint16_t *__restrict__ keys, size_t n, const uint32_t *__r
         uint32_t t[16], sum = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) { t[j] = total[tid * 16 + j]; sum += t[j]; }
-        s_part[tid] = sum;
+        // exclusive prefix of the 256 partial sums: inside the wave by shuffles, across the four waves through LDS
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_part[w] = incl;
         __syncthreads();                               // also: every wave's counts are in s_wave
-        uint32_t run = 0;
-        for (int j = 0; j < tid; ++j) run += s_part[j];
+        uint32_t run = incl - sum;
+        for (int j = 0; j < w; ++j) run += s_part[j];
         const uint32_t *row = hist + (size_t)blockIdx.x * kKeys + tid * 16;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
