@@ -39,8 +39,11 @@ print("4,096-problem windows sorted by ratio          idle %.4f" % idle(windows(
 print("global sort by ratio                           idle %.4f" % idle(np.argsort(ratio, kind="stable")))
 cls = np.where((ratio * 64 >= 0) & (ratio * 64 < 64), np.floor(ratio * 64), 63).astype(np.uint64)
 bits = hi.astype(np.float32).view(np.uint32).astype(np.uint64) >> np.uint64(5)
-shipped = np.argsort((cls << np.uint64(26)) | bits, kind="stable")
-print("schedule.hip: (ratio class, longer length)     idle %.4f" % idle(shipped))
+round2 = np.argsort((cls << np.uint64(26)) | bits, kind="stable")
+print("round 2: 32-bit key (ratio class, length)      idle %.4f" % idle(round2))
+lvl = np.clip((hi.astype(np.float32).view(np.uint32).astype(np.int64) >> 20) - ((127 + 2) << 3), 0, 63)
+shipped = np.argsort((cls.astype(np.int64) << 6) | lvl, kind="stable")
+print("schedule.hip: 12-bit key (64 classes x 64 lvls) idle %.4f" % idle(shipped))
 x = steps[shipped].reshape(-1, 64)
 print("   step counts inside a chunk differ by %.2f on average; chunk maxima %d .. %d" % ((x.max(axis=1) - x.min(axis=1)).mean(), x.max(axis=1).min(), x.max(axis=1).max()))
 print("sorted by the step count itself (bound)        idle %.6f" % idle(np.argsort(steps, kind="stable")))

@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Step-by-step error against the oracle on 4,096 problems with non-zero end velocities (the set of
+test_non_zero_end_velocities_against_oracle), fused k steps and k single steps, plus the halving counts of the worst problem.
+This is the check that caught Cramer's rule losing eps * w^2 at step 2 (profiles/r3_tuning.md): 2.6e-7 on 16 problems, where the
+pivoted elimination stays below 6e-11."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
