@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time rp_batch_set_problems_device (the scheduling pass) alone and followed by the fused solve, 1 Mi problems.
-RP_SCHED_PROBE (tuning builds): bit 0-1: 1 = maps only, 2 = 32-byte records instead of the SoA scatter; bit 2: no prob_of."""
+(The scatter variants listed at the end of profiles/r3_sched_probe.log were tuning builds of schedule.hip measured with this script.)"""
 import os
 import sys
 
@@ -25,7 +25,7 @@ for rep in range(3):
     lead.sync()
     t_s = lead.event_elapsed_ms(0, 1) / len(bs)
     print("set_problems_device alone: %.1f us per batch" % (t_s * 1e3))
-if not os.environ.get("RP_SCHED_PROBE"):
+if True:
     for rep in range(3):
         lead.event_record(0)
         for b in bs:

@@ -143,9 +143,6 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     T best_gap = T(3.0e38);      // stall detector state (off unless kp.stall_window > 0)
     int since_best = 0;
     const T objective_in = t0 + t1;      // the objective (total duration) this launch started from: RP_ST_WRONG_WAY below
-#ifdef RP_UNROLL2
-#pragma unroll 2
-#endif
     const int budget = max_iter - it;      // gated steps this problem may still take: one per-lane counter per step (steps_here) serves both
     for (int s = 0; s < k; ++s) {
         const T gap = current_gap();
