@@ -248,6 +248,36 @@ def test_non_finite_input_is_flagged_not_fatal():
         assert status[1] & rp.ST_NONFINITE and status[1] & rp.ST_MAXITER and it[1] == 30
 
 
+def test_degenerate_problems_are_flagged_and_do_not_disturb_their_neighbours(oracle):
+    # positions that make no problem (NaN, a zero-length segment: the start rule gives duration 0 and the first step divides by
+    # it, unguarded in the reference too) among good ones, through the path a fresh batch takes: scheduling pass (their keys go
+    # to the last ratio class), feasible start formed in registers, fused solve.  They end flagged; every other problem is
+    # solved exactly as in a batch without them.
+    n = 4096 + 77
+    p0, p1, p2 = rp.problems.generate(606, 0, n, rp.problems.DIST_MONOTONE)
+    q0, q1, q2 = p0.copy(), p1.copy(), p2.copy()
+    bad = np.array([5, 64, 1000, 4096, n - 1])
+    q1[bad[0]] = np.nan
+    q1[bad[1]] = q0[bad[1]]                     # first segment empty
+    q2[bad[2]] = q1[bad[2]]                     # second segment empty
+    q0[bad[3]] = q1[bad[3]] = q2[bad[3]] = 7.0   # no trajectory at all
+    q2[bad[4]] = np.inf
+    good = np.ones(n, dtype=bool)
+    good[bad] = False
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        a.solve(1e-8, 40, 0)
+        b.set_problems(q0, q1, q2)
+        b.solve(1e-8, 40, 0)
+        ia, sa = a.get_iters()
+        ib, sb = b.get_iters()
+        xa, xb = a.get_state(), b.get_state()
+    assert np.all(sa == rp.ST_CONVERGED)
+    assert np.array_equal(ib[good], ia[good]) and np.array_equal(sb[good], sa[good]) and np.array_equal(xb[good], xa[good])
+    assert not np.any(sb[bad] & rp.ST_CONVERGED)
+    assert np.all((sb[bad] & (rp.ST_NONFINITE | rp.ST_MAXITER | rp.ST_INFEASIBLE)) != 0), sb[bad]
+
+
 def test_nudges_match_special_keys():
     with rp.Batch(5) as b:
         b.init_default()
