@@ -309,30 +309,31 @@ def test_logical_shards_on_one_device_equal_the_whole_batch(shards):
     assert g == [r["max_residual_sq"], r["max_gap"], r["n_converged"], r["total_steps"]]
 
 
-def test_two_rank_bench_rehearsal_on_one_device_covers_the_whole_batch():
-    # bench.py's N-rank code path with the GPU kernels doing the work: two processes, both on device 0, gloo for the
-    # collectives (RCCL refuses two ranks on one GPU) -- each rank generates and solves ITS contiguous shard of the 2 x 262,144
-    # problems; the all-reduced summary must be that of the unsharded 524,288-problem batch.  (Not a benchmark result.)
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_two_rank_bench_rehearsal_on_one_device_covers_the_whole_batch(ranks):
+    # bench.py's N-rank code path with the GPU kernels doing the work: two (four) processes, all on device 0, gloo for the
+    # collectives (RCCL refuses two ranks on one GPU) -- each rank generates and solves ITS contiguous shard of the 524,288
+    # problems; the all-reduced summary must be that of the unsharded batch.  (Not a benchmark result.)
     # Started as the driver would start the N = 1 case -- `python bench.py --gpus 2 ...` with no RANK in the environment: the
     # parent launches its two ranks itself (torch.distributed.run) and relays rank 0's line.
     import json
     import sys
-    per = 262144
+    per = 524288 // ranks
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--rehearse-on-one-gpu", "--steps", "2",
                           "--warmup", "1", "--problems-per-gpu", str(per), "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "REHEARSAL" in line["data"] and line["cpu_baseline"] is None
-    assert line["self_launched"] is True and line["ranks_in_process_group"] == 2 and "starting 2 ranks" in out.stderr
-    assert line["config"]["problems_total"] == 2 * per and line["config"]["converged_fraction"] == 1.0
-    p0, p1, p2 = rp.problems.generate(12345, 0, 2 * per, rp.problems.DIST_MONOTONE)
-    with rp.Batch(2 * per) as b:
+    assert line["n_gpus"] == ranks and line["scaling"] == "weak" and "REHEARSAL" in line["data"] and line["cpu_baseline"] is None
+    assert line["self_launched"] is True and line["ranks_in_process_group"] == ranks and "starting %d ranks" % ranks in out.stderr
+    assert line["config"]["problems_total"] == ranks * per and line["config"]["converged_fraction"] == 1.0
+    p0, p1, p2 = rp.problems.generate(12345, 0, ranks * per, rp.problems.DIST_MONOTONE)
+    with rp.Batch(ranks * per) as b:
         b.set_problems(p0, p1, p2)
         b.solve(1e-8, 200, 0)
         r = b.reduce()
     g = line["config"]["final_summary"]
-    assert g["n_converged"] == 2 * per and g["total_steps"] == r["total_steps"]
+    assert g["n_converged"] == ranks * per and g["total_steps"] == r["total_steps"]
     assert g["max_gap"] == r["max_gap"] and g["max_residual_sq"] == r["max_residual_sq"]
 
 
