@@ -31,3 +31,41 @@ with rp.Batch(n) as c2, rp.Batch(64, stream=c2.stream()) as tiny:
     run(c2, lambda: (c2.restart(), [tiny.nudge(0, 0.0) for _ in range(200)]), "restart + 200 one-wave dispatches on the same queue")
     run(c2, lambda: (c2.restart(), c2.sync(), time.sleep(0.02)), "restart + 20 ms idle")
     run(c2, lambda: c2.restart(), "restart")
+
+# round 3, second part: kbench.py times the same launch at 0.47 ms where bench.py sees 0.32.  kbench hands its positions over
+# from HOST arrays (rp_batch_set_problems: three hipMemcpyAsync host-to-device on the batch's stream, the scheduling pass, a
+# stream synchronise), bench from device arrays.  Which ingredient is it?
+p0h, p1h, p2h = p0.copy(), p1.copy(), p2.copy()
+with rp.Batch(n) as c3:
+    c3.set_problems_device(*ptrs)
+    c3.restart()
+    c3.sync()
+    run(c3, lambda: c3.restart(), "restart")
+    run(c3, lambda: (c3.set_problems(p0h, p1h, p2h), c3.restart()), "set_problems from HOST arrays + restart")
+    run(c3, lambda: (c3.set_problems(p0h, p1h, p2h), c3.restart(), c3.sync()), "set_problems from HOST arrays + restart + sync")
+    run(c3, lambda: (c3.set_problems(p0h, p1h, p2h), c3.restart(), c3.sync(), time.sleep(0.002)), "... + 2 ms idle")
+    run(c3, lambda: (c3.set_problems_device(*ptrs), c3.restart(), c3.sync()), "set_problems_device + restart + sync")
+    run(c3, lambda: c3.restart(), "restart")
+with rp.Batch(n) as c4:      # a batch with a stream of its own that never saw a host copy, next to one that did
+    c4.set_problems_device(*ptrs)
+    c4.restart()
+    c4.sync()
+    with rp.Batch(n) as other:
+        run(c4, lambda: (other.set_problems(p0h, p1h, p2h), other.sync(), c4.restart()), "restart (ANOTHER batch took host arrays on its own stream)")
+
+# third part: is it simply the FIRST long launch of a freshly created batch (new stream, new memory)?
+keep = []
+for trial in range(4):
+    b = rp.Batch(n)
+    keep.append(b)                      # keep them alive: every batch gets a stream and memory of its own
+    b.set_problems_device(*ptrs)
+    b.restart()
+    b.sync()
+    run(b, lambda: b.restart(), "fresh batch %d (others alive): restart, 6 launches in a row" % trial)
+shared = rp.Batch(n, stream=keep[0].stream())
+shared.set_problems_device(*ptrs)
+shared.restart()
+shared.sync()
+run(shared, lambda: shared.restart(), "fresh batch on an OLD stream (new memory only)")
+for b in keep + [shared]:
+    b.close()

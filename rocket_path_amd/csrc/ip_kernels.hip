@@ -94,7 +94,11 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 // (its stalled problems) and has the registers: affine pieces.  F3 reaches it only after convergence (step ~20 of a fixed-step
 // run); the 44 registers of the pieces would cost every F3 fixed-step kernel a wave per SIMD (k_newton_stream16: 200 -> 3 waves
 // instead of 2), which the HBM-streaming k = 1 launch of a live solve needs more than a converged batch needs cheap halvings.
+#ifdef RP_AFFINE_ALL
+template <int VARIANT> constexpr bool kAffine = true;
+#else
 template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
+#endif
 #ifndef RP_WAVE_LS
 #define RP_WAVE_LS 1      // wave-parallel line search in F4's fixed-step chunk kernel (0: the serial loop, for A/B runs)
 #endif
