@@ -94,7 +94,7 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 // (its stalled problems) and has the registers: affine pieces.  F3 reaches it only after convergence (step ~20 of a fixed-step
 // run); the 44 registers of the pieces would cost every F3 fixed-step kernel a wave per SIMD (k_newton_stream16: 200 -> 3 waves
 // instead of 2), which the HBM-streaming k = 1 launch of a live solve needs more than a converged batch needs cheap halvings.
-#ifdef RP_AFFINE_ALL
+#ifdef RP_AFFINE_ALL      // A/B build (profiles/r3_tuning.md: no gain for F3, 168 VGPRs + 2 spilled in its chunk kernel)
 template <int VARIANT> constexpr bool kAffine = true;
 #else
 template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
