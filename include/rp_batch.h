@@ -133,7 +133,11 @@ RP_API int rp_batch_init_stuck(rp_batch *b);   /* initStuck, onedpath_ip.cpp:177
  * (sorted by expected step count, for the gated solve); callers never see that order except through
  * rp_batch_field_ptr: problem i of every call below is the problem of element i of these arrays. */
 RP_API int rp_batch_set_problems(rp_batch *b, const double *pos0, const double *pos1, const double *pos2);
-/* Same with device-resident inputs (no PCIe in the path). */
+/* Same with device-resident inputs (no PCIe in the path).  Asynchronous: the three arrays are read, in the batch's stream order,
+ * by this call's kernels only (they are copied), so they may be overwritten by later work on that stream.  The call computes the
+ * batch's internal order and stops there: the start state itself is formed in registers by a fused rp_batch_solve
+ * (steps_per_launch <= 0) that follows, or written out by whichever other call touches the state first -- same bits either way,
+ * and nothing a caller can observe except that "positions in, solutions out" costs one launch of state traffic less. */
 RP_API int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double *d_pos1, const double *d_pos2);
 /* Back to the feasible start of the positions the batch already holds (the `I` key for per-problem positions): nothing
  * crosses the boundary.  Asynchronous. */
