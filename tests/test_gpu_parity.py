@@ -725,6 +725,22 @@ def test_launch_shapes_agree_through_the_post_convergence_regime(variant, dtype,
     assert np.array_equal(sa, sb) and np.array_equal(sa, sc) and np.array_equal(sa, sd)
 
 
+def test_f4_fused_steps_with_another_backtrack_factor_equal_single_steps_bitwise():
+    # the wave-parallel service needs the reference's backtrack factor 1/2 (its step lengths s 2^-q are exact); with any other
+    # factor the fused kernel keeps to the wave-uniform lock-step loop, which must still be the serial loop bit for bit
+    n = 4096 * 3 + 5
+    p0, p1, p2 = rp.problems.generate(31337, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F64) as a, rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F64) as b:
+        for x in (a, b):
+            x.set_params(backtrack=0.25, max_backtracks=40)
+            x.set_problems(p0, p1, p2)
+        a.step(24)
+        for _ in range(24):
+            b.step(1)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.all(np.isfinite(sa)) and np.array_equal(sa, sb)
+
+
 # ---------------------------------------------------------------- mu schedule option, F4 settling flag
 def test_mu_mode_defaults_to_the_reference_and_is_validated(g3):
     n = 2048
