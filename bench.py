@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--problems-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the end-to-end path with the batches dealt alternately onto two streams (overlapping kernels: "
+                         "not part of the default run, whose rocprofv3 kernel statistics must stay per-kernel clean)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: run the N-rank code path with every rank on device 0 and gloo for the collectives "
                          "(RCCL refuses two ranks on one GPU); numbers from such a run are not benchmark results")
@@ -394,6 +397,8 @@ def main():
         # caller that pipelines independent batches; wall-clock timed (events of one stream do not span two).
         two = None
         try:
+            if not args.pipelined:
+                raise LookupError("not requested (--pipelined)")
             other = [rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank) for _ in range(1)]
             second = [other[0]] + [rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=other[0].stream())
                                    for _ in range(len(use) // 2 - 1)]
@@ -413,6 +418,8 @@ def main():
                    "note": "wall clock over %d batches alternating between two streams (includes the host's enqueue time)" % len(mixed)}
             for b in second:
                 b.close()
+        except LookupError:
+            two = None
         except Exception as exc:      # an extra: never takes the benchmark down
             two = {"error": str(exc)}
         return {"workload": "per fresh batch of %d problems: rp_batch_set_problems_device (device-resident positions -> scheduled order, "

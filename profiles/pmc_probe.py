@@ -3,8 +3,8 @@
 Every launch whose per-lane-step instruction counts are read from the counters is an ALL-LANES-ACTIVE launch of a
 known number of steps at 1 Mi problems:
     F3 f64          12 fused ungated steps   -> k_steps_chunks<double, double, 3, true>
-    F4 f32          12 fused ungated steps   -> k_steps_chunks<float, float, 4, true>
-    F4 f32 state    12 fused ungated steps   -> k_steps_chunks<float, double, 4, true>
+    F4 f32          50 fused ungated steps   -> k_steps_chunks<float, float, 4, true>     (BASELINE configs[4] itself: F4's line search
+    F4 f32 state    50 fused ungated steps   -> k_steps_chunks<float, double, 4, true>     only sets in from step ~6, so 12 steps undercount)
 then the gated kernel (k_solve_chunks) on 524,288 identical default problems (15 steps each: its instructions per step without idle lanes),
 the benchmark's gated solve (occupancy / busy counters of the real launch) and one k = 1 launch."""
 import os
@@ -16,13 +16,14 @@ import rocket_path_amd as rp  # noqa: E402
 
 N = 1 << 20
 STEPS = 12
+STEPS_F4 = 50
 p0, p1, p2 = rp.problems.generate(12345, 0, N, 0)
 for variant, dtype in ((rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F32), (rp.VARIANT_F4, rp.DTYPE_F32_STATE)):
     with rp.Batch(N, variant, dtype) as b:
         for _ in range(2):
             b.set_problems(p0, p1, p2)
             b.restart()      # the feasible start written out (set_problems defers it to a fused solve)
-            b.step(STEPS)
+            b.step(STEPS if variant == rp.VARIANT_F3 else STEPS_F4)
             b.sync()
 # the gated kernel with every lane doing the same work: 524,288 copies of the default problem (15 steps each, no idle
 # lane-steps), told apart from the benchmark's launch by its grid size

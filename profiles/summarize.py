@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
 sq_dirs = sys.argv[5:]
 N = 1 << 20
-PROBE_STEPS = 12      # profiles/pmc_probe.py
+PROBE_STEPS = 12      # profiles/pmc_probe.py: F3
+PROBE_STEPS_F4 = 50   # ... F4 (all 50 steps of BASELINE configs[4])
 
 
 def one(d, pat):
@@ -100,11 +101,11 @@ for name, c in sq.items():
         c["valu_busy_per_wave_cycle"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
 # flop per lane-step from the ungated 12-step launches of pmc_probe.py (1 Mi problems, every lane active):
 # SQ_INSTS_VALU_* count wave-instructions; x 64 lanes / (12 * 2^20 lane-steps)
-lane_steps = float(PROBE_STEPS) * N
 top = {}
 for name, c in sq.items():
     if not name.startswith("k_steps_chunks") or not name.endswith(", true>"):
         continue
+    lane_steps = float(PROBE_STEPS_F4 if ", 4, true>" in name else PROBE_STEPS) * N
     f64 = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0)
                   + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) / lane_steps
     f32 = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F32", 0) + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_ADD_F32", 0)
@@ -133,10 +134,10 @@ if "SQ_INSTS_VALU" in gated_real:
     top["_valu_wave_insts_per_gated_launch"] = gated_real["SQ_INSTS_VALU"]      # the benchmark's launch itself (idle lanes included)
 sq.update(top)
 json.dump({"_method": "rocprofv3 --pmc <SQ counters, <= 8 per pass> -- python3 profiles/pmc_probe.py (1 Mi problems: 12 fused ungated steps "
-                      "of F3 f64 / F4 f32 / F4 f32-state, then the fused gated F3 solve and one k = 1 launch); SQ_WAVE_CYCLES / "
+                      "of F3 f64, 50 of F4 f32 / F4 f32-state, then the fused gated F3 solve and one k = 1 launch); SQ_WAVE_CYCLES / "
                       "SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles; flop = 2 FMA + MUL + ADD + TRANS wave-instructions x 64 lanes "
-                      "/ (12 x 2^20 lane-steps).  The F4 launches are the FIRST 12 steps from the feasible start (before F4's "
-                      "backtracking regime), so their flop per step undercounts the later steps of a 50-step run", **sq},
+                      "/ (12 x 2^20 lane-steps; F4: 50 x 2^20, all 50 steps of BASELINE configs[4], executed flop of the whole wave-parallel "
+                      "line search included)", **sq},
           open(os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("k_") or "<" not in k}, indent=1)[:3000])
 print(json.dumps(top, indent=1))
