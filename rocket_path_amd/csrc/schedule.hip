@@ -6,7 +6,10 @@
 // is a function of the segment-length ratio r = min|dX| / max|dX| (14 steps for r < 0.5 rising to 18 at r = 1) and, within a
 // ratio class, of the longer segment's length.  A 12-bit key -- 64 ratio classes x 64 length levels, 8 per octave over
 // [4, 1024), clamped outside -- leaves 1.2 % of the lane-steps idle (batch order: 19.2 %; the 32-bit key round 2 sorted on:
-// 1.0 %; 8,192 bins: 0.9 %).
+// 1.0 %; 8,192 bins: 0.9 %).  A problem whose middle node lies OUTSIDE its end nodes (the path reverses; none in the
+// benchmark distribution, a third of the non-monotone stress set) takes 12 steps whatever its ratio and lengths
+// (174,485 of 174,696 such problems; the rest 13), two fewer than any monotone problem: all reversals share key 0.  Without
+// that the stress set idles 12.6 % of its lane-steps, with it 1.2 % (profiles/r3_idle_lanes.log).
 //
 // With 4,096 possible keys the order is ONE stable counting sort, three small hand-written kernels on the batch's own
 // stream (round 2 called rocPRIM's 32-bit radix sort here: 23 dispatches and 188 us at 1 Mi problems for an order whose
@@ -42,9 +45,10 @@ constexpr int kWaveSpan = kTileProblems / kWaves;         // consecutive problem
 
 // key = ratio class (6 bits) : length level (6 bits).  Level = 8 per octave of the longer segment's length from 4 upwards
 // (exponent and top three mantissa bits of its float pattern), clamped to [0, 63].  Equal segments, zero-length pairs and
-// NaN go to the last class.
+// NaN go to the last class; a reversal (segments of opposite sign) has key 0.
 __device__ __forceinline__ uint32_t schedule_key(double p0, double p1, double p2)
 {
+    if ((p1 - p0) * (p2 - p1) < 0.0) return 0u;
     const double d0 = __builtin_fabs(p1 - p0), d1 = __builtin_fabs(p2 - p1);
     const double lo = d0 < d1 ? d0 : d1, hi = d0 < d1 ? d1 : d0;
     const double r = lo / hi * 64.0;

@@ -47,3 +47,19 @@ print("schedule.hip: 12-bit key (64 classes x 64 lvls) idle %.4f" % idle(shipped
 x = steps[shipped].reshape(-1, 64)
 print("   step counts inside a chunk differ by %.2f on average; chunk maxima %d .. %d" % ((x.max(axis=1) - x.min(axis=1)).mean(), x.max(axis=1).min(), x.max(axis=1).max()))
 print("sorted by the step count itself (bound)        idle %.6f" % idle(np.argsort(steps, kind="stable")))
+
+# the other two distributions (2^18 problems each) under the shipped key, with and without its rule for reversals
+N = 1 << 18
+for dist, name in ((rp.problems.DIST_MONOTONE, "monotone"), (rp.problems.DIST_REFERENCE_LIKE, "reference-like"),
+                   (rp.problems.DIST_NON_MONOTONE, "non-monotone")):
+    p0, p1, p2 = rp.problems.generate(12345, 0, N, dist)
+    state = o.batch_init_feasible(3, p0, p1, p2)
+    steps = np.asarray(o.batch_solve_gated(3, state, 1e-8, 200)[0])
+    d0, d1 = np.abs(p1 - p0), np.abs(p2 - p1)
+    lo, hi = np.minimum(d0, d1), np.maximum(d0, d1)
+    cls = np.minimum(np.floor(lo / hi * 64), 63).astype(np.int64)
+    lvl = np.clip((hi.astype(np.float32).view(np.uint32).astype(np.int64) >> 20) - ((127 + 2) << 3), 0, 63)
+    rev = (p1 - p0) * (p2 - p1) < 0
+    print("%-15s reversals %6d (their steps: %s)   idle: problem order %.4f, classes x levels only %.4f, reversals -> key 0 (shipped) %.4f"
+          % (name, rev.sum(), np.unique(steps[rev]).tolist(), idle(np.arange(N)), idle(np.argsort((cls << 6) | lvl, kind="stable")),
+             idle(np.argsort(np.where(rev, 0, (cls << 6) | lvl), kind="stable"))))

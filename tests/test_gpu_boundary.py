@@ -340,7 +340,8 @@ def test_two_rank_bench_rehearsal_on_one_device_covers_the_whole_batch(ranks):
 # ---- the scheduled order inside the batch (csrc/schedule.hip): invisible at the boundary ----
 
 def _schedule_key(p0, p1, p2):
-    """schedule.hip's key: ratio class (6 bits) : length level (6 bits: 8 per octave of the longer segment's length from 4 up)."""
+    """schedule.hip's key: ratio class (6 bits) : length level (6 bits: 8 per octave of the longer segment's length from 4 up);
+    0 for a path that reverses."""
     d0, d1 = np.abs(p1 - p0), np.abs(p2 - p1)
     lo, hi = np.minimum(d0, d1), np.maximum(d0, d1)
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -349,7 +350,9 @@ def _schedule_key(p0, p1, p2):
     length = hi.astype(np.float32)
     lvl = (length.view(np.uint32).astype(np.int64) >> 20) - ((127 + 2) << 3)
     lvl = np.where((length == length) & (length > 0), lvl, 0)
-    return (cls << 6) | np.clip(lvl, 0, 63)
+    with np.errstate(invalid="ignore", over="ignore"):
+        reverses = (p1 - p0) * (p2 - p1) < 0.0
+    return np.where(reverses, 0, (cls << 6) | np.clip(lvl, 0, 63))
 
 
 @pytest.mark.parametrize("n,dist", [(1, 2), (63, 2), (4096, 2), (3 * 4096 + 77, 2), (40 * 4096 + 1, 0), (9000, 1)])
