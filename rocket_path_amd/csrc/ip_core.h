@@ -362,6 +362,7 @@ template <typename T, int VARIANT, bool TRIAL>
 __device__ __forceinline__ void residual_sums(const Acc<T> &e, const T (&lam)[CMap<VARIANT>::NC], const T (&dl)[CMap<VARIANT>::NC], T s, T L,
                                               T &X, T &Q1, T &Q2, T (&cm_out)[4], T (&cp_out)[4])
 {
+    // (one chain per sum: the gated kernels keep three waves on a SIMD and are bound by issue, not by the latency of a chain)
     T rv = T(0), rt0 = T(1), rt1 = T(1), q1m = T(0), q1p = T(0), q2m = T(0), q2p = T(0);
     if constexpr (VARIANT == 3) {
         T d[4];
@@ -376,10 +377,8 @@ __device__ __forceinline__ void residual_sums(const Acc<T> &e, const T (&lam)[CM
             cm_out[j] = cm;
             cp_out[j] = cp;
             const T tm = lm * cm, tp = lp * cp;
-            q1m += tm;
-            q1p += tp;
-            q2m = fma_(tm, tm, q2m);
-            q2p = fma_(tp, tp, q2p);
+            q1m = j == 0 ? tm + tp : (q1m + tm) + tp;
+            q2m = j == 0 ? fma_(tp, tp, tm * tm) : fma_(tp, tp, fma_(tm, tm, q2m));
         }
         // S d_j grad_v a_j with the constant coefficients (-2, 4) / t0, (-4, 2) / t1 folded in (acc_gv): half of it, doubled exactly
         const T rvh = fma_(e.r0, fma_(T(2), d[1], -d[0]), e.r1 * fma_(T(-2), d[2], d[3]));
@@ -399,8 +398,8 @@ __device__ __forceinline__ void residual_sums(const Acc<T> &e, const T (&lam)[CM
         }
     }
     X = fma_(rt1, rt1, fma_(rt0, rt0, rv * rv));
-    Q1 = q1m + q1p;
-    Q2 = q2m + q2p;
+    if constexpr (VARIANT == 3) { Q1 = q1m; Q2 = q2m; }
+    else { Q1 = q1m + q1p; Q2 = q2m + q2p; }
 }
 
 template <typename T, int NC>
@@ -497,14 +496,21 @@ __device__ __forceinline__ void solve_arrow(T a, T b, T c, T d, T e, T rv, T r0,
 // In: point (v; e = values + grads there), multipliers, perturbation p.  Out: dx, d lam.
 // HAVE_C: cm_in / cp_in hold -a_j - L and a_j - L of this very point (gated kernels carry them from the residual sums of the
 // accepted trial); otherwise they are formed here.
+// sg[i]: a number whose SIGN BIT is set iff the full step would drive multiplier i negative (lam_i + dl_i < 0) -- what the
+// fraction-to-boundary rule screens on.  F3 gets it for nothing: lam_i + dl_i = (1/c_i) (lam_i g_i.dx -+ p) and 1/c_i < 0 at a
+// feasible point, so the sign is that of the bracket, an intermediate of dl_i.  `suspect` (F3): some pair product cm cp is
+// not positive, i.e. the point violates a constraint by a rounding (the residual loop accepts points the feasibility loop
+// never saw, as the reference's does) and the sign argument does not hold for that pair: the caller then tests every multiplier.
 template <typename T, int VARIANT, class P, bool HAVE_C = false>
 __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v, const T (&lam)[CMap<VARIANT>::NC],
                                           const Acc<T> &e, T p, T &dxv, T &dx0, T &dx1, T (&dl)[CMap<VARIANT>::NC],
+                                          T (&sg)[CMap<VARIANT>::NC], bool &suspect,
                                           const T *cm_in = nullptr, const T *cp_in = nullptr)
 {
     const T L = kp.limit;
-    T htt[4], htv[4];
-    accel_hess(k, v, e, htt, htv);      // (F3 uses htt only: the mixed second derivatives are constants x 1/t^2, folded in below)
+    [[maybe_unused]] T htt[4], htv[4];
+    if constexpr (VARIANT != 3) accel_hess(k, v, e, htt, htv);      // (F3 folds its second derivatives into the assembly below)
+    suspect = false;
     [[maybe_unused]] T kvv = T(0), kv0 = T(0), kv1 = T(0);
     T k00 = T(0), k11 = T(0);
     [[maybe_unused]] T bv = T(0);
@@ -524,6 +530,11 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
                 cp[j] = HAVE_C ? cp_in[j] : e.a[j] - L;
                 x[j] = fma_(cm[j], cp[j], kp.x_floor);      // the c_guard shift, applied to the pair's product (see c_guard)
             }
+            if constexpr (sizeof(T) == 8)
+                suspect = (int)((unsigned)(__builtin_bit_cast(unsigned long long, x[0]) >> 32) | (unsigned)(__builtin_bit_cast(unsigned long long, x[1]) >> 32) |
+                                (unsigned)(__builtin_bit_cast(unsigned long long, x[2]) >> 32) | (unsigned)(__builtin_bit_cast(unsigned long long, x[3]) >> 32)) < 0;
+            else
+                suspect = (int)(__builtin_bit_cast(unsigned, x[0]) | __builtin_bit_cast(unsigned, x[1]) | __builtin_bit_cast(unsigned, x[2]) | __builtin_bit_cast(unsigned, x[3])) < 0;
             const T x01 = x[0] * x[1], x23 = x[2] * x[3];
             const T iall = rcp_(x01 * x23);
             const T i01 = x23 * iall, i23 = x01 * iall;
@@ -552,8 +563,18 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
         const T kvv_q = fma_(-q1, fma_(T(4), w[2], w[3]), -(q0 * fma_(T(4), w[1], w[0])));                       // kvv / 4
         const T kv0_h = fma_(q0, fma_(T(-2), dlt[1], dlt[0]), r0 * fma_(T(-2), wgt[1], wgt[0]));                  // kv0 / 2
         const T kv1_h = fma_(q1, fma_(T(2), dlt[2], -dlt[3]), r1 * fma_(T(2), wgt[2], -wgt[3]));                  // kv1 / 2
-        k00 = fma_(dlt[0], htt[0], fma_(-wgt[0], e.gt[0], fma_(dlt[1], htt[1], -(wgt[1] * e.gt[1]))));
-        k11 = fma_(dlt[2], htt[2], fma_(-wgt[2], e.gt[2], fma_(dlt[3], htt[3], -(wgt[3] * e.gt[3]))));
+        {
+            // S dlt_j d2a_j/dt2 with the common 1/t^3 taken out of each segment's pair (evalAccelSecondDerivInit / Final,
+            // onedpath_ip.cpp:404-410, 445-451: (36 dX/t - 8 v0 - 4 v1) / t^3 and (-36 dX/t + 4 v0 + 8 v1) / t^3)
+            const T u0 = k.dx0 * r0, u1 = k.dx1 * r1;
+            T m0d, n0d, m1d, n1d;      // 2 m0, 2 n0, 2 m1, 2 n1 of accel_values
+            if constexpr (P::zero_vel) { m0d = T(-4) * v; n0d = T(8) * v; m1d = -n0d; n1d = -m0d; }
+            else { m0d = T(2) * seg0_m<T>(k, v); n0d = T(2) * seg0_n<T>(k, v); m1d = T(2) * seg1_m<T>(k, v); n1d = T(2) * seg1_n<T>(k, v); }
+            const T h0 = fma_(dlt[0], fma_(T(36), u0, m0d), dlt[1] * fma_(T(-36), u0, n0d));
+            const T h1 = fma_(dlt[2], fma_(T(36), u1, m1d), dlt[3] * fma_(T(-36), u1, n1d));
+            k00 = fma_(q0 * r0, h0, fma_(-wgt[0], e.gt[0], -(wgt[1] * e.gt[1])));
+            k11 = fma_(q1 * r1, h1, fma_(-wgt[2], e.gt[2], -(wgt[3] * e.gt[3])));
+        }
         const T bv_h = p * fma_(r0, fma_(T(2), qq[1], -qq[0]), r1 * fma_(T(-2), qq[2], qq[3]));                   // bv / 2
         b0 = fma_(p, fma_(e.gt[0], qq[0], e.gt[1] * qq[1]), T(-1));
         b1 = fma_(p, fma_(e.gt[2], qq[2], e.gt[3] * qq[3]), T(-1));
@@ -565,8 +586,10 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const T lm = lam[2 * j], lp = lam[2 * j + 1];
-            dl[2 * j] = fma_(icm[j], fma_(lm, da[j], -p), -lm);           // -lm + (lm da - p)/cm
-            dl[2 * j + 1] = fma_(-icp[j], fma_(lp, da[j], p), -lp);       // -lp - (lp da + p)/cp
+            sg[2 * j] = fma_(-lm, da[j], p);
+            sg[2 * j + 1] = fma_(lp, da[j], p);
+            dl[2 * j] = fma_(-icm[j], sg[2 * j], -lm);                    // -lm + (lm da - p)/cm
+            dl[2 * j + 1] = fma_(-icp[j], sg[2 * j + 1], -lp);            // -lp - (lp da + p)/cp
         }
     } else {
         T w[4], pc[4], gv[4], gt[4], icv[4];
@@ -607,6 +630,7 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
         for (int i = 0; i < 4; ++i) {
             const T gdx = fma_(gv[i], dxv, gt[i] * (i < 2 ? dx0 : dx1));
             dl[i] = fma_(-w[i], gdx, -(lam[i] + pc[i]));
+            sg[i] = lam[i] + dl[i];
         }
     }
 }
@@ -716,6 +740,8 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
     const T p = gap * kp.inv_mu_den;                      // onedpath_ip.cpp:812
 
     T dxv, dx0, dx1, dl[NC], r0n;
+    T sg[NC];                      // sign bit set: the full step would take multiplier i below zero (see direction)
+    bool suspect = false;
     bool feasible_here = true;
     {
         Acc<T> e;
@@ -731,11 +757,11 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
         }
         if constexpr (MU == 0) {
 #ifndef RP_NO_CARRIED_C      // tuning knob: 18 more VGPRs (146: three waves per SIMD instead of four) for 8 fewer instructions per step
-            if constexpr (SUMS && VARIANT == 3) direction<T, VARIANT, P, true>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, c.cm, c.cp);
+            if constexpr (SUMS && VARIANT == 3) direction<T, VARIANT, P, true>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect, c.cm, c.cp);
 #else
             if constexpr (false) {}
 #endif
-            else direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl);
+            else direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect);
             if constexpr (SUMS) r0n = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
             else r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);      // onedpath_ip.cpp:932
         } else {
@@ -781,45 +807,44 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
             dx0 = fma_(p, dxc[1], dxa[1]);
             dx1 = fma_(p, dxc[2], dxa[2]);
 #pragma unroll
-            for (int i = 0; i < NC; ++i) dl[i] = fma_(p, dlc[i], dla[i]);
+            for (int i = 0; i < NC; ++i) { dl[i] = fma_(p, dlc[i], dla[i]); sg[i] = lam[i] + dl[i]; }
             r0n = residual_norm<T, VARIANT, false>(e, lam, dl, T(0), p, L);
         }
     }
 
     // -- fraction to the boundary on the multipliers (onedpath_ip.cpp:903-915): s = min(1, min_{dl_i < 0} -lam_i/dl_i).
-    // The smallest ratio is found on cross-multiplied pairs (lam_i / e_i < nb / eb  <=>  lam_i eb < nb e_i for
-    // positive denominators; a non-negative dl_i gives e_i <= 0 and never wins, a NaN compares false and is skipped as
-    // std::min skips it) and divided once, instead of eight divisions and a running minimum.
-    // Only a multiplier that the full step would drive negative (lam_i + dl_i < 0, i.e. ratio < 1) can bind, which on
-    // the benchmark distribution happens in steps 1-5 of a solve and for a quarter of the wave-steps: the arg-min runs
-    // behind that screen (a wave whose lanes all pass skips it).
+    // The smallest ratio is found on cross-multiplied pairs (lam_i / -dl_i < nb / -db  <=>  lam_i db > nb dl_i for negative
+    // dl_i, db; a non-negative dl_i never wins against a negative db, a NaN compares false and is skipped as std::min skips
+    // it) and divided once, instead of eight divisions and a running minimum.
+    // Only a multiplier that the full step would drive negative (lam_i + dl_i < 0, i.e. ratio < 1) can bind, which on the
+    // benchmark distribution happens in steps 1-5 of a solve and for a third of the wave-steps -- and then for two or three
+    // of the eight multipliers, the same ones in neighbouring problems of the scheduled order.  So the arg-min runs behind two
+    // screens, both on the sign bits direction() hands over: the lane skips it when no multiplier of its own would go
+    // negative, and inside it the WAVE skips multiplier i when it would in none of its lanes (one compare and a scalar branch
+    // instead of two multiplications, a compare and four selects).  A skipped multiplier has ratio >= 1 and could not have
+    // changed the minimum below 1; a -0 or a NaN with its sign bit set passes the screens and loses the comparison.
     T s = kp.boundary;
     {
-        // "some lam_i + dl_i is negative": the OR of the sums' sign bits instead of a running minimum (a -0 or a NaN with its
-        // sign bit set passes the screen too; the arg-min below then finds no ratio below 1 and leaves s = boundary, exactly as
-        // if it had been skipped)
-        bool any_negative;
-        if constexpr (sizeof(T) == 8) {
-            unsigned bits = 0u;
+        unsigned bits = 0u;
+        unsigned hi[NC];
 #pragma unroll
-            for (int i = 0; i < NC; ++i) bits |= (unsigned)(__builtin_bit_cast(unsigned long long, lam[i] + dl[i]) >> 32);
-            any_negative = (int)bits < 0;
-        } else {
-            unsigned bits = 0u;
-#pragma unroll
-            for (int i = 0; i < NC; ++i) bits |= __builtin_bit_cast(unsigned, lam[i] + dl[i]);
-            any_negative = (int)bits < 0;
+        for (int i = 0; i < NC; ++i) {
+            if constexpr (sizeof(T) == 8) hi[i] = (unsigned)(__builtin_bit_cast(unsigned long long, sg[i]) >> 32);
+            else hi[i] = __builtin_bit_cast(unsigned, sg[i]);
+            bits |= hi[i];
         }
-        if (any_negative) {
-            T nb = T(1), eb = T(1);
+        if ((int)bits < 0 || suspect) {
+            const bool every = __builtin_amdgcn_ballot_w64(suspect) != 0ull;      // a pair product not positive somewhere in the wave: no screen
+            T nb = T(1), db = T(-1);
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-                const T ei = -dl[i];
-                const bool take = lam[i] * eb < nb * ei;
-                nb = take ? lam[i] : nb;
-                eb = take ? ei : eb;
+                if (every || __builtin_amdgcn_ballot_w64((int)hi[i] < 0) != 0ull) {
+                    const bool take = lam[i] * db > nb * dl[i];
+                    nb = take ? lam[i] : nb;
+                    db = take ? dl[i] : db;
+                }
             }
-            s = min_(nb * rcp1_(eb), T(1)) * kp.boundary;
+            s = min_(nb * rcp1_(-db), T(1)) * kp.boundary;
         }
     }
 
@@ -957,6 +982,42 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
                         }
                     }
                 }
+            }
+        }
+    } else if constexpr (!MEMO) {
+        // Kernels without memoisation (the gated ones): the trial point and its accelerations are formed where s changes --
+        // by the feasibility loop, or after a failed residual trial -- so the common case, first trial accepted, runs straight
+        // through with nothing to select.  (The feasibility loop leaves no evaluation only when it ran out of halvings.)
+        if (!et_valid && it < kp.max_bt) {
+            tv = fma_(dxv, s, v);
+            tt0 = fma_(dx0, s, t0);
+            tt1 = fma_(dx1, s, t1);
+            accel_values(k, tv, tt0, tt1, et);
+        }
+        while (it < kp.max_bt) {
+            accel_grads(k, tv, et);
+            diag.moving();
+            T rn;
+            if constexpr (SUMS) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) tl[i] = fma_(dl[i], s, lam[i]);              // kept: the accepted trial IS the update
+                residual_sums<T, VARIANT, false>(et, tl, dl, T(0), L, nc.X, nc.Q1, nc.Q2, nc.cm, nc.cp);   // overwritten by every trial: the accepted one stays
+                rn = residual_from_sums<T, NC>(nc.X, nc.Q1, nc.Q2, p);
+            } else {
+                rn = residual_norm<T, VARIANT, true>(et, lam, dl, s, p, L);
+            }
+            if (rn <= r0n * (T(1) - kp.armijo * s)) {
+                accepted = true;
+                break;
+            }
+            s *= kp.backtrack;
+            diag.resid();
+            ++it;
+            if (it < kp.max_bt) {
+                tv = fma_(dxv, s, v);
+                tt0 = fma_(dx0, s, t0);
+                tt1 = fma_(dx1, s, t1);
+                accel_values(k, tv, tt0, tt1, et);
             }
         }
     } else
