@@ -22,6 +22,8 @@ if mode == "read":
                 if "k_solve_chunks" not in r["Kernel_Name"]:
                     continue
                 agg.setdefault(int(r["Grid_Size"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    agg[int(r["Grid_Size"])].setdefault("_ns", []).append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     for grid, steps, tag in ((N // 2, 15.0 * (N // 2), "identical problems"), (N, 16308345.0, "benchmark batch")):
         c = {k: sum(v) / len(v) for k, v in agg.get(grid, {}).items()}
         if not c:
@@ -31,6 +33,12 @@ if mode == "read":
         print("%-20s VALU/step %.1f  fma %.1f mul %.1f add %.1f trans %.1f  other %.1f  flop/step %.1f  flop/VALU %.2f  SALU/step %.1f" % (
             tag, per("SQ_INSTS_VALU"), fma, mul, add, tr, per("SQ_INSTS_VALU") - fma - mul - add - tr, 2 * fma + mul + add + tr,
             (2 * fma + mul + add + tr) / max(per("SQ_INSTS_VALU"), 1e-9), per("SQ_INSTS_SALU")))
+        if "_ns" in c:
+            # GRBM_GUI_ACTIVE sums the 8 XCDs; SQ_ACTIVE_INST_VALU counts quad-cycles over all SIMDs (1,024); SQ_BUSY_CYCLES sums the 32 shader engines
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+            print("%-20s under the counters: %.1f us, %.0f cycles per XCD = %.2f GHz; vector ALUs busy %.3f of the launch; SQ busy %.3f; LDS instructions active %.4f, waited on %.4f (of wave-cycles)" % (
+                tag, c["_ns"] / 1e3, cyc, cyc / c["_ns"], 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * cyc), c.get("SQ_BUSY_CYCLES", 0.0) / (32.0 * cyc),
+                c.get("SQ_ACTIVE_INST_LDS", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), c.get("SQ_WAIT_INST_LDS", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0)))
     sys.exit(0)
 
 import rocket_path_amd as rp  # noqa: E402

@@ -108,6 +108,19 @@ template <> __device__ __forceinline__ double rcp1_<double>(double x)
 }
 #endif
 template <> __device__ __forceinline__ float rcp1_<float>(float x) { return rcp_<float>(x); }
+// The 32-bit word of x that holds its sign bit, and the OR of three such words as ONE opaque instruction (written in C the
+// compiler widens an OR of high words back into 64-bit ORs of the whole numbers: twice the instructions for the same bit).
+template <typename T> __device__ __forceinline__ unsigned sign_word(T x)
+{
+    if constexpr (sizeof(T) == 8) return (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32);
+    else return __builtin_bit_cast(unsigned, x);
+}
+__device__ __forceinline__ unsigned or3_(unsigned a, unsigned b, unsigned c)
+{
+    unsigned o;
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
 // 1/den, or 0 for a zero denominator (rank-deficient pivot: that component of the step is 0)
 template <typename T> __device__ __forceinline__ T srcp_(T den) { return den != T(0) ? rcp_(den) : T(0); }
 
@@ -498,19 +511,19 @@ __device__ __forceinline__ void solve_arrow(T a, T b, T c, T d, T e, T rv, T r0,
 // accepted trial); otherwise they are formed here.
 // sg[i]: a number whose SIGN BIT is set iff the full step would drive multiplier i negative (lam_i + dl_i < 0) -- what the
 // fraction-to-boundary rule screens on.  F3 gets it for nothing: lam_i + dl_i = (1/c_i) (lam_i g_i.dx -+ p) and 1/c_i < 0 at a
-// feasible point, so the sign is that of the bracket, an intermediate of dl_i.  `suspect` (F3): some pair product cm cp is
+// feasible point, so the sign is that of the bracket, an intermediate of dl_i.  `suspect` (F3; a word whose sign bit says it): some pair product cm cp is
 // not positive, i.e. the point violates a constraint by a rounding (the residual loop accepts points the feasibility loop
 // never saw, as the reference's does) and the sign argument does not hold for that pair: the caller then tests every multiplier.
 template <typename T, int VARIANT, class P, bool HAVE_C = false>
 __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v, const T (&lam)[CMap<VARIANT>::NC],
                                           const Acc<T> &e, T p, T &dxv, T &dx0, T &dx1, T (&dl)[CMap<VARIANT>::NC],
-                                          T (&sg)[CMap<VARIANT>::NC], bool &suspect,
+                                          T (&sg)[CMap<VARIANT>::NC], unsigned &suspect,
                                           const T *cm_in = nullptr, const T *cp_in = nullptr)
 {
     const T L = kp.limit;
     [[maybe_unused]] T htt[4], htv[4];
     if constexpr (VARIANT != 3) accel_hess(k, v, e, htt, htv);      // (F3 folds its second derivatives into the assembly below)
-    suspect = false;
+    suspect = 0u;
     [[maybe_unused]] T kvv = T(0), kv0 = T(0), kv1 = T(0);
     T k00 = T(0), k11 = T(0);
     [[maybe_unused]] T bv = T(0);
@@ -530,11 +543,7 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
                 cp[j] = HAVE_C ? cp_in[j] : e.a[j] - L;
                 x[j] = fma_(cm[j], cp[j], kp.x_floor);      // the c_guard shift, applied to the pair's product (see c_guard)
             }
-            if constexpr (sizeof(T) == 8)
-                suspect = (int)((unsigned)(__builtin_bit_cast(unsigned long long, x[0]) >> 32) | (unsigned)(__builtin_bit_cast(unsigned long long, x[1]) >> 32) |
-                                (unsigned)(__builtin_bit_cast(unsigned long long, x[2]) >> 32) | (unsigned)(__builtin_bit_cast(unsigned long long, x[3]) >> 32)) < 0;
-            else
-                suspect = (int)(__builtin_bit_cast(unsigned, x[0]) | __builtin_bit_cast(unsigned, x[1]) | __builtin_bit_cast(unsigned, x[2]) | __builtin_bit_cast(unsigned, x[3])) < 0;
+            suspect = or3_(sign_word(x[0]), sign_word(x[1]), sign_word(x[2])) | sign_word(x[3]);
             const T x01 = x[0] * x[1], x23 = x[2] * x[3];
             const T iall = rcp_(x01 * x23);
             const T i01 = x23 * iall, i23 = x01 * iall;
@@ -692,6 +701,45 @@ __device__ __forceinline__ void direction_split(const P &k, const KParams<T> &kp
     }
 }
 
+// ---- fraction to the boundary on the multipliers (onedpath_ip.cpp:903-915): s = min(1, min_{dl_i < 0} -lam_i/dl_i).
+// The smallest ratio is found on cross-multiplied pairs (lam_i / -dl_i < nb / -db  <=>  lam_i db > nb dl_i for negative
+// dl_i, db; a non-negative dl_i never wins against a negative db, a NaN compares false and is skipped as std::min skips
+// it) and divided once, instead of eight divisions and a running minimum.
+// Only a multiplier that the full step would drive negative (lam_i + dl_i < 0, i.e. ratio < 1) can bind, which on the
+// benchmark distribution happens in steps 1-5 of a solve and for a third of the wave-steps -- and then for two or three
+// of the eight multipliers, the same ones in neighbouring problems of the scheduled order.  So the arg-min runs behind two
+// screens, both on the sign bits direction() hands over: the lane skips it when no multiplier of its own would go
+// negative, and inside it the WAVE skips multiplier i when it would in none of its lanes (one compare and a scalar branch
+// instead of two multiplications, a compare and four selects).  A skipped multiplier has ratio >= 1 and could not have
+// changed the minimum below 1; a -0 or a NaN with its sign bit set passes the screens and loses the comparison.
+template <typename T, int NC>
+__device__ __forceinline__ T boundary_fraction(const KParams<T> &kp, const T (&lam)[NC], const T (&dl)[NC], const T (&sg)[NC], unsigned suspect)
+{
+    T s = kp.boundary;
+    {
+        unsigned hi[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) hi[i] = sign_word(sg[i]);
+        unsigned bits;
+        if constexpr (NC == 8) bits = or3_(or3_(hi[0], hi[1], hi[2]), or3_(hi[3], hi[4], hi[5]), or3_(hi[6], hi[7], suspect));
+        else bits = or3_(or3_(hi[0], hi[1], hi[2]), hi[3], suspect);
+        if ((int)bits < 0) {
+            const bool every = __builtin_amdgcn_ballot_w64((int)suspect < 0) != 0ull;      // a pair product not positive somewhere in the wave: no screen
+            T nb = T(1), db = T(-1);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if (every || __builtin_amdgcn_ballot_w64((int)hi[i] < 0) != 0ull) {
+                    const bool take = lam[i] * db > nb * dl[i];
+                    nb = take ? lam[i] : nb;
+                    db = take ? dl[i] : db;
+                }
+            }
+            s = min_(nb * rcp1_(-db), T(1)) * kp.boundary;
+        }
+    }
+    return s;
+}
+
 // Line-search bookkeeping for the diagnostic kernel (rp_batch_step_counted): executions of `s *= 0.5` in the feasibility
 // loop (onedpath_ip.cpp:927) and in the residual loop (:944) -- the two numbers the oracle's orc_step_info reports.
 struct NoDiag {
@@ -741,7 +789,7 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
 
     T dxv, dx0, dx1, dl[NC], r0n;
     T sg[NC];                      // sign bit set: the full step would take multiplier i below zero (see direction)
-    bool suspect = false;
+    unsigned suspect = 0u;
     bool feasible_here = true;
     {
         Acc<T> e;
@@ -812,41 +860,7 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
         }
     }
 
-    // -- fraction to the boundary on the multipliers (onedpath_ip.cpp:903-915): s = min(1, min_{dl_i < 0} -lam_i/dl_i).
-    // The smallest ratio is found on cross-multiplied pairs (lam_i / -dl_i < nb / -db  <=>  lam_i db > nb dl_i for negative
-    // dl_i, db; a non-negative dl_i never wins against a negative db, a NaN compares false and is skipped as std::min skips
-    // it) and divided once, instead of eight divisions and a running minimum.
-    // Only a multiplier that the full step would drive negative (lam_i + dl_i < 0, i.e. ratio < 1) can bind, which on the
-    // benchmark distribution happens in steps 1-5 of a solve and for a third of the wave-steps -- and then for two or three
-    // of the eight multipliers, the same ones in neighbouring problems of the scheduled order.  So the arg-min runs behind two
-    // screens, both on the sign bits direction() hands over: the lane skips it when no multiplier of its own would go
-    // negative, and inside it the WAVE skips multiplier i when it would in none of its lanes (one compare and a scalar branch
-    // instead of two multiplications, a compare and four selects).  A skipped multiplier has ratio >= 1 and could not have
-    // changed the minimum below 1; a -0 or a NaN with its sign bit set passes the screens and loses the comparison.
-    T s = kp.boundary;
-    {
-        unsigned bits = 0u;
-        unsigned hi[NC];
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            if constexpr (sizeof(T) == 8) hi[i] = (unsigned)(__builtin_bit_cast(unsigned long long, sg[i]) >> 32);
-            else hi[i] = __builtin_bit_cast(unsigned, sg[i]);
-            bits |= hi[i];
-        }
-        if ((int)bits < 0 || suspect) {
-            const bool every = __builtin_amdgcn_ballot_w64(suspect) != 0ull;      // a pair product not positive somewhere in the wave: no screen
-            T nb = T(1), db = T(-1);
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                if (every || __builtin_amdgcn_ballot_w64((int)hi[i] < 0) != 0ull) {
-                    const bool take = lam[i] * db > nb * dl[i];
-                    nb = take ? lam[i] : nb;
-                    db = take ? dl[i] : db;
-                }
-            }
-            s = min_(nb * rcp1_(-db), T(1)) * kp.boundary;
-        }
-    }
+    T s = boundary_fraction<T, NC>(kp, lam, dl, sg, suspect);      // onedpath_ip.cpp:903-915
 
     // -- backtrack until primal feasible (onedpath_ip.cpp:919-928) --
     Acc<T> et;                 // evaluation at the current trial point
@@ -1199,6 +1213,103 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 #pragma unroll
     for (int i = 0; i < NC; ++i) lam[i] = nlam[i];
     c = nc;
+}
+
+// ---- the same step IN PLACE, for the gated solve ----------------------------------------------------------------------
+// newton_step_to keeps the point and multipliers a step starts from next to the trial it is evaluating (a rejected trial is
+// followed by another from the same start), so an accepted trial has to be MOVED into the registers the next step reads: 11
+// 64-bit moves per step on a kernel that is bound by vector-instruction issue.  Here the trial overwrites the state (a
+// multiply-add onto itself) and the start of the step waits in LDS instead -- 11 ds_write per step, which issue on the
+// LDS port beside the other waves' arithmetic -- to be read back only when a trial is rejected (one step in five has a
+// rejected feasibility trial, a rejected residual trial is rare before convergence).  Same functions, same operands, same
+// order of decisions as newton_step_to<MEMO = false, MU = 0>: every bit of every iterate is the same.
+// bk: this lane's column of the block's backup area, field q at bk[q * 64]; volatile so that the compiler neither forwards the
+// stored values to the reads (keeping them in registers is what this form is there to avoid) nor drops the stores.
+// The loops are written with the trial formed where s is set (at the bottom, from the backed-up start), so that a trial
+// is a multiply-add INTO the state registers.
+template <typename T> using LdsBackup = __attribute__((address_space(3))) volatile T *;      // LDS address space kept in the type: ds_read / ds_write, not flat accesses
+
+template <typename T, int VARIANT, class P>
+__device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T> &kp, T gap, T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
+                                                    AccCarry<T, true, true> &c, LdsBackup<T> bk)
+{
+    constexpr int NC = CMap<VARIANT>::NC;
+    const T L = kp.limit;
+    const T p = gap * kp.inv_mu_den;                      // onedpath_ip.cpp:812
+
+    T dxv, dx0, dx1, dl[NC], sg[NC];
+    unsigned suspect = 0u;
+    {
+        Acc<T> e;
+        e.r0 = c.r0; e.r1 = c.r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { e.a[j] = c.a[j]; e.gt[j] = c.gt[j]; }
+        if constexpr (VARIANT == 3) direction<T, VARIANT, P, true>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect, c.cm, c.cp);
+        else direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect);
+    }
+    const T r0n = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);      // onedpath_ip.cpp:932
+    bk[0 * 64] = v; bk[1 * 64] = t0; bk[2 * 64] = t1;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) bk[(3 + i) * 64] = lam[i];
+
+    T s = boundary_fraction<T, NC>(kp, lam, dl, sg, suspect);         // onedpath_ip.cpp:903-915
+
+    // Both loops are WAVE-UNIFORM: they run while any lane is still searching, a lane that is done sits out under the
+    // execution mask.  (A loop that lanes leave one by one makes the compiler copy every value that is live after it -- the
+    // state -- at every trip, for the lanes that have left: the 11 moves per step this form is there to avoid.)
+    // -- backtrack until primal feasible (onedpath_ip.cpp:919-928); a trial is formed where s is set --
+    Acc<T> et;
+    v = fma_(dxv, s, v);
+    t0 = fma_(dx0, s, t0);
+    t1 = fma_(dx1, s, t1);
+    {
+        bool open = true;
+        int it = 0;
+        do {
+            if (open) {
+                accel_values(k, v, t0, t1, et);
+                if (all_satisfied<T, VARIANT>(et, L) || !(it < kp.max_bt)) {      // (out of halvings: the reference goes on with an s it has not tested)
+                    open = false;
+                } else {
+                    s *= kp.backtrack;
+                    ++it;
+                    v = fma_(dxv, s, bk[0 * 64]);
+                    t0 = fma_(dx0, s, bk[1 * 64]);
+                    t1 = fma_(dx1, s, bk[2 * 64]);
+                }
+            }
+        } while (__builtin_amdgcn_ballot_w64(open) != 0ull);
+    }
+    // -- backtrack until the residual decreases (onedpath_ip.cpp:932-945), and take the step (:949-952): the trial that ends
+    // the loop -- accepted, or the last s, which the reference takes untested -- is the new state, its sums the next step's --
+    {
+        bool open = true;
+        int it = 0;
+        do {
+            if (open) {
+                accel_grads(k, v, et);
+#pragma unroll
+                for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
+                residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);      // (r0n and the direction have taken what they needed from c)
+                const T rn = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
+                if (rn <= r0n * (T(1) - kp.armijo * s) || !(it < kp.max_bt)) {
+                    open = false;
+                } else {
+                    s *= kp.backtrack;
+                    ++it;
+                    v = fma_(dxv, s, bk[0 * 64]);
+                    t0 = fma_(dx0, s, bk[1 * 64]);
+                    t1 = fma_(dx1, s, bk[2 * 64]);
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) lam[i] = bk[(3 + i) * 64];
+                    accel_values(k, v, t0, t1, et);
+                }
+            }
+        } while (__builtin_amdgcn_ballot_w64(open) != 0ull);
+    }
+    c.r0 = et.r0; c.r1 = et.r1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c.a[j] = et.a[j]; c.gt[j] = et.gt[j]; }
 }
 
 // the common call: no bookkeeping

@@ -102,6 +102,9 @@ template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
 #ifndef RP_WAVE_LS
 #define RP_WAVE_LS 1      // wave-parallel line search in F4's fixed-step chunk kernel (0: the serial loop, for A/B runs)
 #endif
+#ifndef RP_GATED_IN_PLACE
+#define RP_GATED_IN_PLACE 1     // the gated kernel's step overwrites the state, its start backed up in LDS (0: newton_step_to, for A/B runs)
+#endif
 #ifndef RP_TILED_WAVES
 #define RP_TILED_WAVES 3     // the large-batch kernels fit 168 VGPRs (gated solve: 146, fixed steps: 152-158)
 #endif
@@ -117,7 +120,7 @@ template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
 template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
-                                         int &it, uint32_t &st, int &steps_here, bool &still_open, D &diag)
+                                         int &it, uint32_t &st, int &steps_here, bool &still_open, D &diag, LdsBackup<T> backup = nullptr)
 {
     static_assert(!(WAVE && GATED), "lanes of a gated solve leave the loop at different steps");
     // gated kernels carry the time derivatives as well (newton_step's MEMO = !GATED) and, in the reference's mu mode, the
@@ -148,17 +151,40 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     int since_best = 0;
     const T objective_in = t0 + t1;      // the objective (total duration) this launch started from: RP_ST_WRONG_WAY below
     const int budget = max_iter - it;      // gated steps this problem may still take: one per-lane counter per step (steps_here) serves both
+    if constexpr (GATED) {
+        // Wave-uniform loop: it runs while any lane of the wave still has steps to take, and a lane that has reached its gate
+        // sits the rest out under the execution mask.  (Lanes leaving a loop one by one make the compiler copy every value that
+        // is live after it -- the whole state -- at every trip.)
+        bool open = true;
+        for (int s = 0; s < k; ++s) {
+            if (open) {
+                const T gap = current_gap();
+                if (gap < tol) { st |= RP_ST_CONVERGED; done = true; open = false; }
+                else if (steps_here >= budget) { st |= RP_ST_MAXITER; done = true; open = false; }
+                else if (STALL && kp.stall_window > 0) {
+                    if (gap < T(0.5) * best_gap) { best_gap = gap; since_best = 0; }
+                    else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; open = false; }
+                }
+                if (open) {
+                    if constexpr (MU == 0 && std::is_same<D, NoDiag>::value && RP_GATED_IN_PLACE)
+                        newton_step_inplace<T, VARIANT, P>(pr, kp, gap, v, t0, t1, lam, e, backup);      // the step's start waits in LDS, the accepted trial is the state
+                    else
+                        newton_step<T, VARIANT, P, false, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);      // gated solves never reach the regime the memoisation is for
+                    if constexpr (sizeof(S) != sizeof(T)) {
+                        v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
+#pragma unroll
+                        for (int c = 0; c < CMap<VARIANT>::NC; ++c) lam[c] = (T)(S)lam[c];
+                        evaluate();                      // the carried evaluation belongs to the unrounded point
+                    }
+                    ++steps_here;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(open) == 0ull) break;
+        }
+    } else
     for (int s = 0; s < k; ++s) {
         const T gap = current_gap();
-        if (GATED) {
-            if (gap < tol) { st |= RP_ST_CONVERGED; done = true; break; }
-            if (steps_here >= budget) { st |= RP_ST_MAXITER; done = true; break; }
-            if (STALL && kp.stall_window > 0) {
-                if (gap < T(0.5) * best_gap) { best_gap = gap; since_best = 0; }
-                else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; break; }
-            }
-        }
-        newton_step<T, VARIANT, P, !GATED, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);      // gated solves never reach the regime the memoisation is for
+        newton_step<T, VARIANT, P, true, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);
         if constexpr (sizeof(S) != sizeof(T)) {
             v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
 #pragma unroll
@@ -190,10 +216,10 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
 template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, bool WAVE = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
-                                         int &it, uint32_t &st, int &steps_here, bool &still_open)
+                                         int &it, uint32_t &st, int &steps_here, bool &still_open, LdsBackup<T> backup = nullptr)
 {
     NoDiag none;
-    run_lane<T, VARIANT, GATED, STALL, P, S, AFFINE, MU, NoDiag, WAVE>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open, none);
+    run_lane<T, VARIANT, GATED, STALL, P, S, AFFINE, MU, NoDiag, WAVE>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open, none, backup);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -261,6 +287,8 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     if (__ballot(active) == 0) return;      // a chunk that finished in an earlier launch
     int steps_here = 0;
     bool still_open = false;
+    // where the in-place step (newton_step_inplace) parks the point and multipliers a step started from: 11 (F4: 7) fields x 64 lanes
+    __shared__ T s_backup[(MU == 0 && RP_GATED_IN_PLACE) ? (3 + NC) * 64 : 1];
 
     if (active) {
         S *f = base + i;
@@ -295,7 +323,8 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
             pr.dx0 = p1 - p0;
             pr.dx1 = p2 - p1;
         }
-        run_lane<T, VARIANT, true, STALL, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, true, STALL, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open,
+                                                                     (LdsBackup<T>)&s_backup[(MU == 0 && RP_GATED_IN_PLACE) ? threadIdx.x : 0]);
         // the store addresses are formed only now (the barrier keeps the compiler from holding them in registers across the steps)
         size_t j = (size_t)chunk * 64 + threadIdx.x;
         asm volatile("" : "+v"(j));
