@@ -160,6 +160,17 @@ template <typename T, bool ZV = false> struct Prob {
     T v0, v2;      // vel0X, vel2X (unused when ZV)
     T dx0, dx1;    // pos1X - pos0X, pos2X - pos1X
 };
+// The same with the two deltas parked in LDS (the gated kernel, which needs its registers for a fourth wave per SIMD): a use is
+// a ds_read, which issues beside the arithmetic.  `at` points at this lane's value; volatile for the same reason as LdsBackup.
+template <typename T> struct LdsConst {
+    __attribute__((address_space(3))) volatile T *at;
+    __device__ __forceinline__ operator T() const { return *at; }
+};
+template <typename T, bool ZV = false> struct ProbLds {
+    static constexpr bool zero_vel = ZV;
+    T v0, v2;
+    LdsConst<T> dx0, dx1;
+};
 // The velocity combinations of the four end accelerations (v0*-4 + v1*-2 etc., onedpath_ip.cpp:387, 428).  With zero end
 // velocities they are multiples of vel1 by powers of two, formed once (v2 = 2v, v4 = 4v, v8 = 8v: exact) and signed for free.
 template <typename T, class P> __device__ __forceinline__ T seg0_m(const P &k, T v) { if constexpr (P::zero_vel) return -(v + v); else return fma_(T(-4), k.v0, T(-2) * v); }   // v0*-4 + v1*-2
@@ -201,15 +212,16 @@ template <int VARIANT> struct CMap;
 template <> struct CMap<3> { static constexpr int NC = 8; };   // onedpath_ip.cpp:101
 template <> struct CMap<4> { static constexpr int NC = 4; };   // onedpath2_ip.cpp
 
-// accelerations only: enough for constraintsSatisfied (onedpath_ip.cpp:738-751)
+// accelerations only: enough for constraintsSatisfied (onedpath_ip.cpp:738-751); u0, u1 = dX / t come back for accel_grads_u
 template <typename T, class P>
-__device__ __forceinline__ void accel_values(const P &k, T v, T t0, T t1, Acc<T> &e)
+__device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, T &u0, T &u1)
 {
     const T rr = rcp_(t0 * t1);                               // one reciprocal for both durations: 1/t0 = t1/(t0 t1)
     const T r0 = t1 * rr, r1 = t0 * rr;
     e.r0 = r0;
     e.r1 = r1;
-    const T u0 = k.dx0 * r0, u1 = k.dx1 * r1;                 // dX / t
+    u0 = k.dx0 * r0;                                          // dX / t
+    u1 = k.dx1 * r1;
     const T m0 = seg0_m<T>(k, v), n0 = seg0_n<T>(k, v);       // segment 0: v1 = vel1
     const T m1 = seg1_m<T>(k, v), n1 = seg1_n<T>(k, v);       // segment 1: v0 = vel1
     e.a[0] = fma_(T(6), u0, m0) * r0;
@@ -217,13 +229,18 @@ __device__ __forceinline__ void accel_values(const P &k, T v, T t0, T t1, Acc<T>
     e.a[2] = fma_(T(6), u1, m1) * r1;
     e.a[3] = fma_(T(-6), u1, n1) * r1;
 }
-
-// first derivatives, from the reciprocals already in e (dAdT, dAdV0/dAdV1 of :389-391, :430-432)
 template <typename T, class P>
-__device__ __forceinline__ void accel_grads(const P &k, T v, Acc<T> &e)
+__device__ __forceinline__ void accel_values(const P &k, T v, T t0, T t1, Acc<T> &e)
+{
+    T u0, u1;
+    accel_values_u(k, v, t0, t1, e, u0, u1);
+}
+
+// first derivatives, from the reciprocals already in e (dAdT, dAdV0/dAdV1 of :389-391, :430-432) and u = dX / t of the same point
+template <typename T, class P>
+__device__ __forceinline__ void accel_grads_u(const P &k, T v, Acc<T> &e, T u0, T u1)
 {
     const T r0 = e.r0, r1 = e.r1;
-    const T u0 = k.dx0 * r0, u1 = k.dx1 * r1;
     const T m0 = seg0_m<T>(k, v), n0 = seg0_n<T>(k, v);
     const T m1 = seg1_m<T>(k, v), n1 = seg1_n<T>(k, v);
     const T q0 = r0 * r0, q1 = r1 * r1;
@@ -231,6 +248,11 @@ __device__ __forceinline__ void accel_grads(const P &k, T v, Acc<T> &e)
     e.gt[1] = fma_(T(12), u0, -n0) * q0;
     e.gt[2] = fma_(T(-12), u1, -m1) * q1;
     e.gt[3] = fma_(T(12), u1, -n1) * q1;
+}
+template <typename T, class P>
+__device__ __forceinline__ void accel_grads(const P &k, T v, Acc<T> &e)
+{
+    accel_grads_u(k, v, e, k.dx0 * e.r0, k.dx1 * e.r1);
 }
 
 // second derivatives (evalAccelSecondDerivInit / Final, onedpath_ip.cpp:394-411, 435-452)
@@ -1259,6 +1281,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
     // state -- at every trip, for the lanes that have left: the 11 moves per step this form is there to avoid.)
     // -- backtrack until primal feasible (onedpath_ip.cpp:919-928); a trial is formed where s is set --
     Acc<T> et;
+    T u0, u1;      // dX / t of the trial point et belongs to
     v = fma_(dxv, s, v);
     t0 = fma_(dx0, s, t0);
     t1 = fma_(dx1, s, t1);
@@ -1267,7 +1290,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
         int it = 0;
         do {
             if (open) {
-                accel_values(k, v, t0, t1, et);
+                accel_values_u(k, v, t0, t1, et, u0, u1);
                 if (all_satisfied<T, VARIANT>(et, L) || !(it < kp.max_bt)) {      // (out of halvings: the reference goes on with an s it has not tested)
                     open = false;
                 } else {
@@ -1287,7 +1310,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
         int it = 0;
         do {
             if (open) {
-                accel_grads(k, v, et);
+                accel_grads_u(k, v, et, u0, u1);
 #pragma unroll
                 for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
                 residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);      // (r0n and the direction have taken what they needed from c)
@@ -1302,7 +1325,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                     t1 = fma_(dx1, s, bk[2 * 64]);
 #pragma unroll
                     for (int i = 0; i < NC; ++i) lam[i] = bk[(3 + i) * 64];
-                    accel_values(k, v, t0, t1, et);
+                    accel_values_u(k, v, t0, t1, et, u0, u1);
                 }
             }
         } while (__builtin_amdgcn_ballot_w64(open) != 0ull);

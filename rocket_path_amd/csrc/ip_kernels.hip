@@ -87,7 +87,9 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
 #define RP_NEWTON_WAVES 2     // minimum waves per SIMD the register allocator must leave room for
 #endif
 #ifndef RP_GATED_WAVES
-#define RP_GATED_WAVES 3     // tuning knob: 4 (128 VGPRs, 6 spilled) and 2 were measured, DESIGN.md tuning log
+#define RP_GATED_WAVES 4     // 128 VGPRs: the in-place step with the cold values parked in LDS fits without a spill in the loop; 1 Mi problems = 16,384
+                             // waves = exactly four full rounds of the chip's 4,096 wave slots (three per SIMD: 5.33 rounds).  The stall-detector
+                             // twin (two more live values, 10 spilled at 128) stays at three
 #endif
 // Which residual-loop form the fixed-step kernels use once the trial point has become x (newton_step's AFFINE): every kernel of
 // a variant uses the same one, so that all launch shapes agree bit for bit.  F4 reaches that regime within a dozen steps
@@ -150,7 +152,9 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     T best_gap = T(3.0e38);      // stall detector state (off unless kp.stall_window > 0)
     int since_best = 0;
     const T objective_in = t0 + t1;      // the objective (total duration) this launch started from: RP_ST_WRONG_WAY below
-    const int budget = max_iter - it;      // gated steps this problem may still take: one per-lane counter per step (steps_here) serves both
+    [[maybe_unused]] int left = max_iter - it;      // GATED: steps this problem may still take -- the ONE per-lane counter of the solve (it = max_iter - left
+                                                    // afterwards; the caller has the count it came in with and takes the difference as steps_here)
+    [[maybe_unused]] int taken = 0;                 // (STALL only: whether this launch moved the problem at all)
     if constexpr (GATED) {
         // Wave-uniform loop: it runs while any lane of the wave still has steps to take, and a lane that has reached its gate
         // sits the rest out under the execution mask.  (Lanes leaving a loop one by one make the compiler copy every value that
@@ -160,7 +164,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
             if (open) {
                 const T gap = current_gap();
                 if (gap < tol) { st |= RP_ST_CONVERGED; done = true; open = false; }
-                else if (steps_here >= budget) { st |= RP_ST_MAXITER; done = true; open = false; }
+                else if (left <= 0) { st |= RP_ST_MAXITER; done = true; open = false; }
                 else if (STALL && kp.stall_window > 0) {
                     if (gap < T(0.5) * best_gap) { best_gap = gap; since_best = 0; }
                     else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; open = false; }
@@ -176,7 +180,8 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                         for (int c = 0; c < CMap<VARIANT>::NC; ++c) lam[c] = (T)(S)lam[c];
                         evaluate();                      // the carried evaluation belongs to the unrounded point
                     }
-                    ++steps_here;
+                    --left;
+                    if constexpr (STALL) ++taken;
                 }
             }
             if (__builtin_amdgcn_ballot_w64(open) == 0ull) break;
@@ -193,21 +198,31 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
         }
         ++steps_here;
     }
-    it += steps_here;
+    if constexpr (GATED) it = max_iter - left;
+    else it += steps_here;
     if (GATED) {
         if (!done) {   // settle the status now so the host knows whether to launch again
             const T gap = current_gap();
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; }
-            else if (it >= max_iter) { st |= RP_ST_MAXITER; done = true; }
+            else if (left <= 0) { st |= RP_ST_MAXITER; done = true; }
         }
         st &= ~(RP_ST_NONFINITE | RP_ST_INFEASIBLE);
         // F4 "tends to settle the wrong direction" (README.md:34): from the feasible start its total duration GROWS (7.0 ->
         // 7.07 on the default problem, optimum 4.0) while the gap sticks near 0.47.  With the stall detector on, a problem that
         // stops unconverged with an objective no better than the one this launch started from is flagged.
-        if (STALL && kp.stall_window > 0 && steps_here > 0 && !(st & RP_ST_CONVERGED) && !(t0 + t1 < objective_in)) st |= RP_ST_WRONG_WAY;
+        if (STALL && kp.stall_window > 0 && taken > 0 && !(st & RP_ST_CONVERGED) && !(t0 + t1 < objective_in)) st |= RP_ST_WRONG_WAY;
         if (st & RP_ST_CONVERGED) st &= ~RP_ST_WRONG_WAY;      // the flag is per launch: a short launch (host-polled rounds) may not lower the objective of a problem that converges later
         if (!(finite_(v) && finite_(t0) && finite_(t1))) st |= RP_ST_NONFINITE;
-        if (!all_satisfied<T, VARIANT, Carry>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
+        if constexpr (Carry::has_sums && VARIANT == 3) {
+            // from the carried constraint values -a - L, a - L (exact signs: a floating-point difference has the sign of the
+            // comparison of its operands), so that the accelerations themselves need not stay in registers through the solve
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ok = ok && !(e.cm[j] > T(0)) && !(e.cp[j] > T(0));
+            if (!ok) st |= RP_ST_INFEASIBLE;
+        } else {
+            if (!all_satisfied<T, VARIANT, Carry>(e, kp.limit)) st |= RP_ST_INFEASIBLE;
+        }
         still_open = !done;
     }
 }
@@ -265,7 +280,7 @@ __device__ unsigned long long g_trace[4 * 32768];
 // kernel would read back, and the progress words' clearing pass.
 // (mu_mode 1 carries the split direction: ~210 VGPRs, two waves per SIMD)
 template <typename S, typename T, int VARIANT, bool STALL, bool ZV, int MU = 0, bool START = false>
-__global__ void __launch_bounds__(64, MU == 1 ? RP_NEWTON_WAVES : RP_GATED_WAVES)
+__global__ void __launch_bounds__(64, MU == 1 ? RP_NEWTON_WAVES : (STALL && RP_GATED_WAVES > 3) ? 3 : RP_GATED_WAVES)
 k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
                int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
                const StartRecord *__restrict__ records, const uint32_t *__restrict__ prob_of, double start_limit)
@@ -288,7 +303,9 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     int steps_here = 0;
     bool still_open = false;
     // where the in-place step (newton_step_inplace) parks the point and multipliers a step started from: 11 (F4: 7) fields x 64 lanes
-    __shared__ T s_backup[(MU == 0 && RP_GATED_IN_PLACE) ? (3 + NC) * 64 : 1];
+    // ... and the problem's two deltas (ProbLds): 13 (9) fields
+    constexpr bool kInPlace = MU == 0 && RP_GATED_IN_PLACE;
+    __shared__ T s_backup[kInPlace ? (3 + NC + 2) * 64 : 1];
 
     if (active) {
         S *f = base + i;
@@ -323,11 +340,42 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
             pr.dx0 = p1 - p0;
             pr.dx1 = p2 - p1;
         }
-        run_lane<T, VARIANT, true, STALL, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open,
-                                                                     (LdsBackup<T>)&s_backup[(MU == 0 && RP_GATED_IN_PLACE) ? threadIdx.x : 0]);
-        // the store addresses are formed only now (the barrier keeps the compiler from holding them in registers across the steps)
-        size_t j = (size_t)chunk * 64 + threadIdx.x;
+        // The iteration count and the status word are not held through the steps: the lane takes its budget and a clean flag word
+        // in, and both are read again (START: known) when the results are merged below.
+        int it_new = it;
+        uint32_t flags = 0;
+        if constexpr (kInPlace) {
+            LdsBackup<T> col = (LdsBackup<T>)&s_backup[threadIdx.x];
+            col[(3 + NC) * 64] = pr.dx0;
+            col[(3 + NC + 1) * 64] = pr.dx1;
+            ProbLds<T, ZV> pl;
+            if constexpr (!ZV) { pl.v0 = pr.v0; pl.v2 = pr.v2; }
+            pl.dx0.at = col + (3 + NC) * 64;
+            pl.dx1.at = col + (3 + NC + 1) * 64;
+            NoDiag none;
+            run_lane<T, VARIANT, true, STALL, ProbLds<T, ZV>, S, false, MU, NoDiag, false>(pl, kp, k, tol, max_iter, v, t0, t1, lam, it_new, flags, steps_here, still_open, none, col);
+        } else {
+            run_lane<T, VARIANT, true, STALL, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it_new, flags, steps_here, still_open);
+        }
+        // the store addresses are formed only now (the barrier keeps the compiler from holding them in registers across the steps),
+        // from the lane number the hardware counts rather than the thread index that came in a register
+        unsigned zero = 0u;
+        asm volatile("" : "+v"(zero));      // (opaque, or the count is merged with one taken before the steps and held in a register through them)
+        size_t j = (size_t)chunk * 64 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
         asm volatile("" : "+v"(j));
+        if constexpr (START) {
+            steps_here = it_new;
+            it = it_new;
+            st = flags;
+        } else {
+            steps_here = it_new - *(volatile int32_t *)(iters + j);
+            it = it_new;
+            // run_lane clears NONFINITE / INFEASIBLE (re-derived from the final point) and, on convergence, WRONG_WAY; everything else of the old word stays
+            uint32_t old = *(volatile uint32_t *)(status + j);
+            old &= ~(RP_ST_NONFINITE | RP_ST_INFEASIBLE);
+            if (flags & RP_ST_CONVERGED) old &= ~RP_ST_WRONG_WAY;
+            st = old | flags;
+        }
         iters[j] = it;
         status[j] = st;
         if (START || steps_here > 0) {

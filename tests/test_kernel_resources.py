@@ -1,6 +1,7 @@
 """Register / scratch budget of the headline kernels, checked at compile time (hipcc cross-compiles gfx950
-without a GPU).  Any scratch (spilled VGPRs) makes the fused solve's launch time erratic, and more than 168
-VGPRs costs the third resident wave per SIMD -- both were measured, see DESIGN.md's tuning log."""
+without a GPU).  Any scratch (spilled VGPRs) makes the fused solve's launch time erratic; the gated solve is built for
+FOUR resident waves per SIMD (128 VGPRs: its step works in place, the cold values wait in LDS), its fixed-step sibling for
+three (168) -- all measured, see DESIGN.md's tuning log."""
 import os
 import re
 import shutil
@@ -13,7 +14,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
-def test_headline_kernels_fit_three_waves_without_scratch():
+def test_headline_kernels_fit_their_waves_without_scratch():
     src = os.path.join(ROOT, "rocket_path_amd", "csrc", "ip_kernels.hip")
     r = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off",
                         "-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.devnull, src],
@@ -36,11 +37,14 @@ def test_headline_kernels_fit_three_waves_without_scratch():
     fixed = {k: v for k, v in usage.items() if "k_steps_chunksIddLi3ELb1E" in k}
     assert len(gated) == 2 and len(fixed) == 1, sorted(usage)
     for k, v in list(gated.items()) + list(fixed.items()):
-        assert v["VGPRs"] <= 168, (k, v)
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (k, v)
-        assert 3 * v["LDS Size [bytes/block]"] <= 160 * 1024, (k, v)
-    for k, v in list(gated.items()) + list(fixed.items()):
-        assert v["LDS Size [bytes/block]"] == 0, (k, v)      # state goes from HBM to registers and back, nothing staged
+    for k, v in gated.items():
+        assert v["VGPRs"] <= 128, (k, v)                              # four waves per SIMD
+        assert v["LDS Size [bytes/block]"] == 13 * 64 * 8, (k, v)      # the step's start (11 fields) + the problem's two deltas, per lane
+        assert 16 * v["LDS Size [bytes/block]"] <= 160 * 1024, (k, v)  # ... for all 16 single-wave blocks of a CU
+    for k, v in fixed.items():
+        assert v["VGPRs"] <= 168, (k, v)
+        assert v["LDS Size [bytes/block]"] == 0, (k, v)               # state goes from HBM to registers and back, nothing staged
     # nothing on the Newton path may spill in its default build
     checked = 0
     for k, v in usage.items():
