@@ -71,6 +71,10 @@ template <typename T> __device__ __forceinline__ T min_(T a, T b);      // NaN i
 template <> __device__ __forceinline__ double min_<double>(double a, double b) { return __builtin_fmin(a, b); }
 template <> __device__ __forceinline__ float min_<float>(float a, float b) { return __builtin_fminf(a, b); }
 
+template <typename T> __device__ __forceinline__ T max_(T a, T b);      // NaN in one operand -> the other
+template <> __device__ __forceinline__ double max_<double>(double a, double b) { return __builtin_fmax(a, b); }
+template <> __device__ __forceinline__ float max_<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+
 template <typename T> __device__ __forceinline__ bool finite_(T a) { return abs_(a) <= T(1.7976931348623157e308) && a == a; }
 template <> __device__ __forceinline__ bool finite_<float>(float a) { return abs_(a) <= 3.4028234e38f && a == a; }
 
@@ -84,7 +88,9 @@ template <> __device__ __forceinline__ double rcp_<double>(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#ifndef RP_RCP_ONE_STEP      // A/B knob: one refinement only (<= 10 ulp instead of IEEE 1/x)
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#endif
     return r;
 }
 template <> __device__ __forceinline__ float rcp_<float>(float x)
@@ -330,6 +336,33 @@ __device__ __forceinline__ bool all_satisfied(const A &e, T L)
         for (int i = 0; i < 4; ++i) ok = ok && !(e.a[i] * e.a[i] > l2);
     }
     return ok;
+}
+
+// "This trial point violates an acceleration limit BEYOND DOUBT" -- a division-free proof, used to walk the feasibility loop
+// (onedpath_ip.cpp:919-928) past the halvings whose verdict cannot be in question.  F4 never converges: it sits on an
+// acceleration limit with a Newton direction that points outward, and on alternate steps the reference halves the step 12 to 19
+// times before the trial point is back inside -- the violation shrinks with s, |a| / L - 1 ~ c 2^-k at the k-th halving, and stays
+// far above rounding until the very end.  In exact arithmetic the four end accelerations are
+//     a_0 = (6 dX0 + m0 t0) / t0^2,  a_1 = (-6 dX0 + n0 t0) / t0^2   (and the same with dX1, m1, n1, t1 for segment 1),
+// m, n the velocity combinations of accel_values, so |a_j| > L  <=>  |N_j| > L t^2 with the numerators N_j: four multiply-adds
+// and two squares where the evaluation proper costs a reciprocal and 20 operations.  The evaluation proper computes
+// a_j = ((+-6 (dX r) + m) r) with r = 1/t good to 3 eps, i.e. with an absolute error below 8 eps (|6 dX| / t^2 + |a_j|); N_j and
+// L t^2 here carry 2 eps (|N_j| + |6 dX|) and 2 eps L t^2.  The proof therefore demands
+//     |N_j| > L t^2 (1 + 64 eps) + 64 eps |6 dX|,
+// several times the sum of both errors: whenever it holds, the evaluation proper finds |a_j| > L as well (and so, up to the
+// rounding-level differences the parity tests measure anyway, does the reference: constraintsSatisfied, error > 0).  Anything
+// else -- including NaNs, which compare false -- is left to the evaluation proper.  No decision changes; trials whose outcome
+// is certain are not evaluated.
+template <typename T, class P>
+__device__ __forceinline__ bool infeasible_beyond_doubt(const P &k, T L, T v, T t0, T t1)
+{
+    constexpr T margin = sizeof(T) == 8 ? T(64.0 * 2.220446049250313e-16) : T(64.0 * 1.1920929e-7);
+    const T six0 = T(6) * k.dx0, six1 = T(6) * k.dx1;
+    const T lim = L * (T(1) + margin);
+    const T b0 = fma_(lim, t0 * t0, margin * abs_(six0)), b1 = fma_(lim, t1 * t1, margin * abs_(six1));
+    const T n0 = max_(abs_(fma_(seg0_m<T>(k, v), t0, six0)), abs_(fma_(seg0_n<T>(k, v), t0, -six0)));
+    const T n1 = max_(abs_(fma_(seg1_m<T>(k, v), t1, six1)), abs_(fma_(seg1_n<T>(k, v), t1, -six1)));
+    return n0 > b0 || n1 > b1;
 }
 
 // surrogateDualityGap (onedpath_ip.cpp:794-808)
@@ -601,8 +634,12 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
             T m0d, n0d, m1d, n1d;      // 2 m0, 2 n0, 2 m1, 2 n1 of accel_values
             if constexpr (P::zero_vel) { m0d = T(-4) * v; n0d = T(8) * v; m1d = -n0d; n1d = -m0d; }
             else { m0d = T(2) * seg0_m<T>(k, v); n0d = T(2) * seg0_n<T>(k, v); m1d = T(2) * seg1_m<T>(k, v); n1d = T(2) * seg1_n<T>(k, v); }
-            const T h0 = fma_(dlt[0], fma_(T(36), u0, m0d), dlt[1] * fma_(T(-36), u0, n0d));
-            const T h1 = fma_(dlt[2], fma_(T(36), u1, m1d), dlt[3] * fma_(T(-36), u1, n1d));
+            // (36 is no inline constant: as a literal the multiply-add has to be the two-address form, which overwrites its
+            // addend, and each addend is needed twice -- from a scalar register it is the three-address form, no copies)
+            T c36 = T(36);
+            asm("" : "+s"(c36));
+            const T h0 = fma_(dlt[0], fma_(c36, u0, m0d), dlt[1] * fma_(-c36, u0, n0d));
+            const T h1 = fma_(dlt[2], fma_(c36, u1, m1d), dlt[3] * fma_(-c36, u1, n1d));
             k00 = fma_(q0 * r0, h0, fma_(-wgt[0], e.gt[0], -(wgt[1] * e.gt[1])));
             k11 = fma_(q1 * r1, h1, fma_(-wgt[2], e.gt[2], -(wgt[3] * e.gt[3])));
         }
@@ -776,6 +813,10 @@ struct HalvingDiag {
     __device__ __forceinline__ void moving() { ++nm; }
 };
 
+#ifndef RP_FEAS_SCREEN
+#define RP_FEAS_SCREEN 1      // F4: walk the feasibility loop past trials that are infeasible beyond doubt (0: evaluate every trial, for A/B runs)
+#endif
+
 // ---- one Newton step -------------------------------------------------------------------
 // In:  x = (v, t0, t1), lam, c = reciprocals + accelerations at x, gap = surrogate duality gap at x.
 // Out: the same at the new point (the caller recomputes the gap from c).
@@ -888,7 +929,25 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
     Acc<T> et;                 // evaluation at the current trial point
     T tv = v, tt0 = t0, tt1 = t1;
     bool et_valid = false;     // et holds the accelerations of (tv,tt0,tt1) == x + s*dx
-    for (int it = 0; it < kp.max_bt; ++it) {
+    int it_feas = 0;
+    // (not in the one instantiation that has no registers for it -- double precision with non-zero end velocities, 167 of the 168
+    // three waves allow: the proof changes no decision, so leaving it out there changes no result either)
+    if constexpr (VARIANT == 4 && RP_FEAS_SCREEN && (P::zero_vel || sizeof(T) == 4)) {
+        // the halvings whose trial misses the limits beyond doubt (infeasible_beyond_doubt): the reference evaluates them, finds an
+        // error > 0 and halves; this halves.  Wave-uniform, every lane to its first trial that needs a proper look.
+        bool more = true;
+        do {
+            if (more) {
+                more = it_feas < kp.max_bt && infeasible_beyond_doubt<T, P>(k, L, fma_(dxv, s, v), fma_(dx0, s, t0), fma_(dx1, s, t1));
+                if (more) {
+                    s *= kp.backtrack;
+                    ++it_feas;
+                    diag.feas();
+                }
+            }
+        } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
+    }
+    for (int it = it_feas; it < kp.max_bt; ++it) {
         tv = fma_(dxv, s, v);
         tt0 = fma_(dx0, s, t0);
         tt1 = fma_(dx1, s, t1);
