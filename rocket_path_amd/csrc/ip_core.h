@@ -430,7 +430,7 @@ template <typename T, int VARIANT, bool TRIAL>
 __device__ __forceinline__ void residual_sums(const Acc<T> &e, const T (&lam)[CMap<VARIANT>::NC], const T (&dl)[CMap<VARIANT>::NC], T s, T L,
                                               T &X, T &Q1, T &Q2, T (&cm_out)[4], T (&cp_out)[4])
 {
-    // (one chain per sum: the gated kernels keep three waves on a SIMD and are bound by issue, not by the latency of a chain)
+    // (one chain per sum: the gated kernels keep four waves on a SIMD and are bound by issue, not by the latency of a chain)
     T rv = T(0), rt0 = T(1), rt1 = T(1), q1m = T(0), q1p = T(0), q2m = T(0), q2p = T(0);
     if constexpr (VARIANT == 3) {
         T d[4];
@@ -867,7 +867,7 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
             for (int j = 0; j < 4; ++j) e.gt[j] = c.gt[j];
         }
         if constexpr (MU == 0) {
-#ifndef RP_NO_CARRIED_C      // tuning knob: 18 more VGPRs (146: three waves per SIMD instead of four) for 8 fewer instructions per step
+#ifndef RP_NO_CARRIED_C      // tuning knob of newton_step_to (A/B builds with RP_GATED_IN_PLACE=0): 18 more VGPRs for 8 fewer instructions per step
             if constexpr (SUMS && VARIANT == 3) direction<T, VARIANT, P, true>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect, c.cm, c.cp);
 #else
             if constexpr (false) {}

@@ -16,8 +16,8 @@
 //
 // Launch shapes, all sharing the per-lane step of ip_core.h:
 //   k_solve_chunks     the gated solve (the benchmark's kernel): one 64-problem chunk of the scheduled order per
-//                      single-wave block, state in registers from its first load to its last store, no LDS, longest
-//                      chunks dispatched first
+//                      single-wave block, state in registers from its first load to its last store (LDS only as the in-place
+//                      step's backup column, no staging), longest chunks dispatched first
 //   k_steps_chunks     k >= 2 ungated steps: the same shape, fixed step count
 //   k_newton_stream16  k = 1 (one launch per Newton step), the HBM-streaming form: 16 B per lane (two doubles / four floats =
 //                      that many consecutive problems per lane), one global_load/store_dwordx4 per field
@@ -108,7 +108,7 @@ template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
 #define RP_GATED_IN_PLACE 1     // the gated kernel's step overwrites the state, its start backed up in LDS (0: newton_step_to, for A/B runs)
 #endif
 #ifndef RP_TILED_WAVES
-#define RP_TILED_WAVES 3     // the large-batch kernels fit 168 VGPRs (gated solve: 146, fixed steps: 152-158)
+#define RP_TILED_WAVES 3     // the fixed-step large-batch kernels fit 168 VGPRs (152-166); the gated solve has its own bound, RP_GATED_WAVES
 #endif
 
 // The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
@@ -243,7 +243,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
 // has converged and gated step counts differ from problem to problem (12-20 on the benchmark distribution), so in arbitrary
 // order ~20 % of the lane-steps of a fused solve are idle.  The batch is therefore kept in scheduled order (see the top
 // of this file) and each single-wave block takes one 64-problem chunk of it: lanes of similar expected length, loaded and
-// stored as full coalesced segments with no LDS and no block barrier in between.  With one wave per block the hardware
+// stored as full coalesced segments with no staging and no block barrier in between.  With one wave per block the hardware
 // dispatcher IS the work queue: a wave that finishes early frees its slot for the next chunk, so the tail of the grid is
 // one chunk long instead of one 512-problem tile (which cost 11 % at 1 Mi problems: 2,048 tiles over 768 slots), and
 // the blocks walk the order from its end, so the longest chunks start first.
