@@ -161,8 +161,11 @@ template <typename T> struct KParams {
 // selects the general instantiation.  With ZV the two fields are neither read nor held, and the four velocity
 // combinations lose a multiply-add each; the results are bit-identical to the general code on zero inputs
 // (fma(c, 0, x) == x exactly).
-template <typename T, bool ZV = false> struct Prob {
+// LEAN: the instantiating kernel has no registers to spare (F4 in double precision with double storage, 166 of the 168 that three
+// waves allow): optional accelerators that change no result (ray_proof) are left out.
+template <typename T, bool ZV = false, bool LEAN = false> struct Prob {
     static constexpr bool zero_vel = ZV;
+    static constexpr bool lean = LEAN;
     T v0, v2;      // vel0X, vel2X (unused when ZV)
     T dx0, dx1;    // pos1X - pos0X, pos2X - pos1X
 };
@@ -174,6 +177,7 @@ template <typename T> struct LdsConst {
 };
 template <typename T, bool ZV = false> struct ProbLds {
     static constexpr bool zero_vel = ZV;
+    static constexpr bool lean = false;
     T v0, v2;
     LdsConst<T> dx0, dx1;
 };
@@ -363,6 +367,63 @@ __device__ __forceinline__ bool infeasible_beyond_doubt(const P &k, T L, T v, T 
     const T n0 = max_(abs_(fma_(seg0_m<T>(k, v), t0, six0)), abs_(fma_(seg0_n<T>(k, v), t0, -six0)));
     const T n1 = max_(abs_(fma_(seg1_m<T>(k, v), t1, six1)), abs_(fma_(seg1_n<T>(k, v), t1, -six1)));
     return n0 > b0 || n1 > b1;
+}
+
+// The same proof along the whole ray x + s dx, for ONE limit, in closed form.  In 99.4 % of F4's long halving sequences the
+// limit that is still broken at the last rejected trial is broken at every trial before it (oracle trajectories,
+// profiles/r3_tuning.md), and along the ray its numerator and L t^2 are quadratics in s:
+//     N(s) = S + (M0 + s M1)(T0 + s T1),      M0 = m(v) (the velocity combination at x), M1 = B dv, (T0, T1) = (t, dt) of the
+//     segment, S = +-6 dX;      the proof's condition   sg N(s) > L (1 + 64 eps) T(s)^2 + 64 eps |6 dX|
+// is g(s) = g0 + s (g1 + s g2) > 0 with three coefficients per lane: two multiply-adds and a compare per halving instead of the 21
+// instructions of infeasible_beyond_doubt.  Which limit: the one most broken at a probe point eight halvings down the ray (none
+// broken there: no closed form for this lane, the per-trial proof takes over); sg = the sign of its numerator there.
+// Rounding: the six coefficients carry at most 3 eps of their terms each, Horner's rule 2 eps, and the trial point the loop would
+// really form (a rounded multiply-add per coordinate) moves N and L T^2 by 2 eps of theirs: all below 8 eps Q with
+//     Q = |S| + (|M0| + s |M1|)(|T0| + s |T1|) + L (|T0| + s |T1|)^2 at the first, largest s;
+// 32 eps Q is subtracted from g0.  Where g(s) > 0 the per-trial proof's condition holds for the point the loop would form, so
+// the evaluation proper would find the limit broken (see infeasible_beyond_doubt): the halving is certain.
+template <typename T> struct RayProof {
+    T g0, g1, g2;
+    bool on;
+    __device__ __forceinline__ bool holds(T s) const { return fma_(fma_(g2, s, g1), s, g0) > T(0); }
+};
+template <typename T, class P>
+__device__ __forceinline__ RayProof<T> ray_proof(const P &k, T L, T v, T t0, T t1, T dv, T d0, T d1, T s)
+{
+    constexpr T eps = sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-7);
+    constexpr T margin = T(64) * eps;
+    const T lim = L * (T(1) + margin);
+    const T six0 = T(6) * k.dx0, six1 = T(6) * k.dx1;
+    // the probe: which limit is (most) broken eight halvings down the ray
+    const T sp = ldexp_(s, -8);
+    const T pv = fma_(dv, sp, v), p0 = fma_(d0, sp, t0), p1 = fma_(d1, sp, t1);
+    const T n0 = fma_(seg0_m<T>(k, pv), p0, six0), n1 = fma_(seg0_n<T>(k, pv), p0, -six0);
+    const T n2 = fma_(seg1_m<T>(k, pv), p1, six1), n3 = fma_(seg1_n<T>(k, pv), p1, -six1);
+    const T b0 = fma_(lim, p0 * p0, margin * abs_(six0)), b1 = fma_(lim, p1 * p1, margin * abs_(six1));
+    const T e0 = abs_(n0) - b0, e1 = abs_(n1) - b0, e2 = abs_(n2) - b1, e3 = abs_(n3) - b1;
+    const T e01 = max_(e0, e1), e23 = max_(e2, e3);
+    const bool seg = e23 > e01;                       // segment 1
+    const bool fin = seg ? e3 > e2 : e1 > e0;         // the final end of that segment
+    RayProof<T> r;
+    r.on = max_(e01, e23) > T(0);
+    // that limit's line: N(s) = S + (M0 + s M1)(T0 + s T1)
+    const T T0 = seg ? t1 : t0, T1 = seg ? d1 : d0;
+    const T six = seg ? six1 : six0;
+    const T S = fin ? -six : six;
+    const T M0 = seg ? (fin ? seg1_n<T>(k, v) : seg1_m<T>(k, v)) : (fin ? seg0_n<T>(k, v) : seg0_m<T>(k, v));
+    const T B = seg ? (fin ? T(2) : T(-4)) : (fin ? T(4) : T(-2));      // d m / d vel1 of seg0_m, seg0_n, seg1_m, seg1_n
+    const T M1 = B * dv;
+    const T nsel = seg ? (fin ? n3 : n2) : (fin ? n1 : n0);
+    const T sg = nsel < T(0) ? T(-1) : T(1);
+    const T c0 = fma_(M0, T0, S), c1 = fma_(M0, T1, M1 * T0), c2 = M1 * T1;
+    const T lt1 = lim * T1;
+    const T q0 = fma_(lim * T0, T0, margin * abs_(six)), q1 = (lim * T0) * (T1 + T1), q2 = lt1 * T1;
+    const T ta = fma_(s, abs_(T1), abs_(T0));                            // |T0| + s |T1|
+    const T Q = abs_(six) + fma_(fma_(s, abs_(M1), abs_(M0)), ta, (L * ta) * ta);
+    r.g0 = fma_(sg, c0, -q0) - (T(32) * eps) * Q;
+    r.g1 = fma_(sg, c1, -q1);
+    r.g2 = fma_(sg, c2, -q2);
+    return r;
 }
 
 // surrogateDualityGap (onedpath_ip.cpp:794-808)
@@ -816,6 +877,9 @@ struct HalvingDiag {
 #ifndef RP_FEAS_SCREEN
 #define RP_FEAS_SCREEN 1      // F4: walk the feasibility loop past trials that are infeasible beyond doubt (0: evaluate every trial, for A/B runs)
 #endif
+#ifndef RP_FEAS_RAY
+#define RP_FEAS_RAY 1         // ... first in closed form along the ray (0: trial by trial only)
+#endif
 
 // ---- one Newton step -------------------------------------------------------------------
 // In:  x = (v, t0, t1), lam, c = reciprocals + accelerations at x, gap = surrogate duality gap at x.
@@ -933,8 +997,36 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
     // (not in the one instantiation that has no registers for it -- double precision with non-zero end velocities, 167 of the 168
     // three waves allow: the proof changes no decision, so leaving it out there changes no result either)
     if constexpr (VARIANT == 4 && RP_FEAS_SCREEN && (P::zero_vel || sizeof(T) == 4)) {
-        // the halvings whose trial misses the limits beyond doubt (infeasible_beyond_doubt): the reference evaluates them, finds an
-        // error > 0 and halves; this halves.  Wave-uniform, every lane to its first trial that needs a proper look.
+        // the halvings whose trial misses the limits beyond doubt: the reference evaluates them, finds an error > 0 and halves; this
+        // halves.  Wave-uniform loops, every lane to its first trial that needs a proper look: first along the ray in closed form
+        // for the one limit that stays broken longest (ray_proof), then trial by trial for all four (infeasible_beyond_doubt).
+        if constexpr (RP_FEAS_RAY && !P::lean) {
+            const RayProof<T> ray = ray_proof<T, P>(k, L, v, t0, t1, dxv, dx0, dx1, s);
+            if (kp.backtrack == T(0.5)) {
+                // The number of proven halvings by bisection, no loop over them.  g is a quadratic with g(0) <= 0 wherever x itself is
+                // not beyond doubt infeasible: if g(s) > 0 at the first trial, g > 0 exactly on the trials down to a root and <= 0 below
+                // it (convex: g increases beyond its one positive root; concave: g >= the smaller of two positive values in
+                // between), so "g(s 2^-k) > 0" is true up to some k and false from there on.  Seven probes find the last true k in
+                // [0, 127]; every counted halving lies between two EVALUATED positives.  (g(0) > 0: all 127 hold, the budget caps it.)
+                int last = 0;
+#pragma unroll
+                for (int b = 64; b >= 1; b >>= 1) last += ray.holds(ldexp_(s, -(last + b))) ? b : 0;
+                int proven = (ray.on && ray.holds(s)) ? last + 1 : 0;
+                proven = proven < kp.max_bt ? proven : kp.max_bt;
+                s = ldexp_(s, -proven);
+                it_feas = proven;
+                if constexpr (!std::is_same<D, NoDiag>::value)
+                    for (int q = 0; q < proven; ++q) diag.feas();
+            } else {
+                bool more = ray.on;
+                while (__builtin_amdgcn_ballot_w64(more) != 0ull) {      // (branch-free body: two multiply-adds, a compare, the selects)
+                    more = more && it_feas < kp.max_bt && ray.holds(s);
+                    s *= more ? kp.backtrack : T(1);
+                    it_feas += more ? 1 : 0;
+                    if (more) diag.feas();
+                }
+            }
+        }
         bool more = true;
         do {
             if (more) {

@@ -417,7 +417,8 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     T lam[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) lam[c] = (T)ld_once(f + (3 + c) * stride);
-    Prob<T, ZV> pr;
+    using Pk = Prob<T, ZV, VARIANT == 4 && sizeof(S) == 8 && sizeof(T) == 8>;
+    Pk pr;
     {
         const T p0 = (T)f[(CB + 0) * stride], p1 = (T)f[(CB + 2) * stride], p2 = (T)f[(CB + 3) * stride];
         if constexpr (!ZV) {
@@ -432,7 +433,7 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     bool still_open = false;
     // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
     // its stalled problems), so all its fixed-step kernels use it and agree bit for bit; F3's would spill at three waves
-    run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>, 0, RP_WAVE_LS && (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+    run_lane<T, VARIANT, false, false, Pk, S, kAffine<VARIANT>, 0, RP_WAVE_LS && (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
     // the store addresses are formed only now: the barrier keeps the compiler from holding eleven of them in registers
     // across the steps (168 VGPRs and 4-10 spilled without it, 152 with it)
     size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
