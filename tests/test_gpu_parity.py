@@ -914,6 +914,36 @@ def test_halving_counts_on_the_other_distributions_and_f4(oracle, variant, dist,
     assert serr(st[:, :3], aos[:, :3]) < (TOL if variant == rp.VARIANT_F3 else 1e-5)
 
 
+def test_f4_halving_counts_in_the_long_sequence_regime(oracle):
+    # From step ~10 on F4 halves the step 12-19 times at every other step of a problem.  The device walks those sequences
+    # without evaluating their trials: the number of halvings that are infeasible beyond doubt comes from a closed form along
+    # the ray (ip_core.h: ray_proof, bisection over the count), the next few from a division-free per-trial proof
+    # (infeasible_beyond_doubt), the last one or two from the evaluation proper.  One step from states the ORACLE reached after
+    # 24 steps: both halving counts of every problem against the oracle's.
+    n = 2048
+    p0, p1, p2 = rp.problems.generate(2718, 0, n, rp.problems.DIST_MONOTONE)
+    aos = oracle.batch_init_feasible(rp.VARIANT_F4, p0, p1, p2)
+    oracle.batch_steps(rp.VARIANT_F4, aos, 24)
+    info = StepInfo()
+    with rp.Batch(n, rp.VARIANT_F4) as a:
+        a.set_state(aos)
+        nf, nr = a.step_counted(1)
+        got = a.get_state()
+    exp_nf, exp_nr = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        oracle.step(rp.VARIANT_F4, aos[i], info)
+        exp_nf[i], exp_nr[i] = info.feas_halvings, info.resid_halvings
+    long_ones = exp_nf >= 10
+    assert long_ones.sum() > n // 4 and exp_nf.max() >= 17            # the regime was reached
+    assert np.array_equal(nf, exp_nf), "%d feasibility counts differ" % int((nf != exp_nf).sum())
+    # the residual loop of a stalled F4 problem ends where s dr drops below the rounding of |r|^2 (~50 halvings): that last-bit
+    # decision differs between the condensed 3 x 3 solve and the reference's QR on a few problems per thousand (6 of 2,048
+    # measured), as in F3's post-convergence regime (profiles/r2_halving_probe.log); the feasibility counts above do not
+    same = nr == exp_nr
+    assert same.sum() >= n - n // 100, "%d residual counts differ" % int((~same).sum())
+    assert serr(got[same, :3], aos[same, :3]) < 1e-9
+
+
 @pytest.mark.parametrize("dtype", [rp.DTYPE_F64, rp.DTYPE_F32_STATE, rp.DTYPE_F32])
 def test_f4_wave_parallel_line_search_equals_single_steps_bitwise(dtype):
     # F4's fused fixed-step launches serve the stragglers of the residual loop with the whole wave (newton_step_to, WAVE:
