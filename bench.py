@@ -570,6 +570,56 @@ def main():
                                    "feasibility halvings and up to 33 residual halvings per step from step ~6 on: F4 stalls, "
                                    "README.md:34), which is why a fused step costs several times a k = 1 step"}
 
+        # (d) the rows either side of the path: the plot-data kernel on a solved batch (66 positions + 4 accelerations per
+        #     problem into device memory: 48 B of state + 4 B of slot map read, 560 B written) and the feasibility move
+        #     (moveTowardFeasibility, the Space key) on the same number of starts pushed out of the feasible set
+        with rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) as c6:
+            c6.set_problems_device(*ptrs)
+            c6.solve(GAP_TOL, MAX_ITER, 0)
+            d_plot = torch.empty((count, 66), dtype=torch.float64, device=torch.device("cuda", local_rank))
+            d_acc = torch.empty((count, 4), dtype=torch.float64, device=torch.device("cuda", local_rank))
+            ms = []
+            for _ in range(5):
+                c6.sync()
+                c6.event_record(4)
+                c6.sample_device(d_plot.data_ptr(), d_acc.data_ptr())
+                c6.event_record(5)
+                c6.sync()
+                ms.append(c6.event_elapsed_ms(4, 5))
+            t_s = min(ms[1:])
+            del d_plot, d_acc
+        b_sample = 6 * 8 + 4 + 70 * 8      # six fields (the end velocities are zero and not read) + the slot map word in, 70 doubles out
+        n7 = count
+        with rp.Batch(n7, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) as c7:
+            c7.set_problems_device(*ptrs)
+            c7.restart()
+            st = c7.get_state()
+            st[:, 1] *= 0.7      # both durations too short: all four end accelerations beyond the limit
+            st[:, 2] *= 0.7
+            ms = []
+            for _ in range(4):
+                c7.set_state(st)
+                c7.sync()
+                c7.event_record(4)
+                c7.move_toward_feasibility()
+                c7.event_record(5)
+                c7.sync()
+                ms.append(c7.event_elapsed_ms(4, 5))
+            t_f = min(ms[1:])
+        line["neighbours"] = {
+            "workload": "SURVEY 8f rows 1 and 3: plot data of %d solved problems into device memory (k_sample); feasibility move of %d infeasible "
+                        "starts (k_feasibility_move: four violated rows each, the rank-deficient branch of the QR)" % (count, n7),
+            "sample": {"ms": t_s, "problems_per_s": count / (t_s * 1e-3),
+                       "roofline": {"bound": "hbm", "bytes_moved_per_problem": b_sample, "achieved": b_sample * count / (t_s * 1e-3) / 1e9,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_sample * count / (t_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "output rows are in problem order, the state in scheduled order: the six fields are gathered, one "
+                                            "32-byte sector each (192 B of read traffic per problem for 48 B used); on 756 B of sector traffic the "
+                                            "same launch is %.0f GB/s" % (756.0 * count / (t_s * 1e-3) / 1e9)}},
+            "feasibility_move": {"ms": t_f, "problems_per_s": n7 / (t_f * 1e-3),
+                                 "hbm_GBps_on_136_B_per_problem": 136.0 * n7 / (t_f * 1e-3) / 1e9,
+                                 "note": "16 fields read, 3 written per problem; the arithmetic (Gram matrix, Eigen-ordered 4 x 4 column-pivoted "
+                                         "Householder QR in double precision, one problem per lane) is what the launch time is made of"}}
+
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(count, 1 << 19))
     else:

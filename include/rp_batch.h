@@ -190,6 +190,10 @@ RP_API int rp_batch_summary_read(rp_batch *b, rp_reduction *out);
  * positions (33 per segment) and 4 end accelerations, host arrays, synchronous. */
 RP_API int rp_batch_sample(rp_batch *b, double *pos66, double *acc4);
 
+/* The same into DEVICE memory the caller owns (n x 66 and n x 4 doubles), asynchronously on the batch stream: for a consumer
+ * that draws from device memory, and what bench.py times (nothing crosses PCIe). */
+RP_API int rp_batch_sample_device(rp_batch *b, double *d_pos66, double *d_acc4);
+
 /* The same for problems [first, first + count) only (what onDraw needs for the watched problem). Synchronous. */
 RP_API int rp_batch_sample_range(rp_batch *b, size_t first, size_t count, double *pos66, double *acc4);
 /* The rest of printState for problems [first, first + count): `Surrogate gap` and the `Constraints:` table

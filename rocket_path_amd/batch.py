@@ -147,6 +147,10 @@ class Batch:
         capi.check(self._lib.rp_batch_sample(self._h, _ptr(pos), _ptr(acc)))
         return pos, acc
 
+    def sample_device(self, d_pos66, d_acc4):
+        """The same into device memory (addresses of n x 66 and n x 4 doubles), asynchronously on the batch stream."""
+        capi.check(self._lib.rp_batch_sample_device(self._h, ctypes.c_void_p(d_pos66), ctypes.c_void_p(d_acc4)))
+
     def sample_range(self, first, count):
         pos = np.empty((count, 66), dtype=np.float64)
         acc = np.empty((count, 4), dtype=np.float64)

@@ -74,6 +74,7 @@ SIGNATURES = {
     "rp_batch_summary_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "rp_batch_summary_read": (ctypes.c_int, [_vp, ctypes.POINTER(Reduction)]),
     "rp_batch_sample": (ctypes.c_int, [_vp, _vp, _vp]),
+    "rp_batch_sample_device": (ctypes.c_int, [_vp, _vp, _vp]),
     "rp_batch_sample_range": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "rp_batch_constraints_range": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _vp]),
     "rp_batch_sync": (ctypes.c_int, [_vp]),

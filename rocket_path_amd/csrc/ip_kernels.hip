@@ -881,44 +881,66 @@ k_move_toward_feasibility(S *__restrict__ base, size_t stride, size_t n, KParams
     }
 }
 
-// Plot data: one thread per output value.  Per problem 66 positions (drawSegment,
-// onedpath_ip.cpp:1065-1088, 33 per segment) and 4 end accelerations (plotAcceleration, 1024-1027).
-template <typename T, int VARIANT>
+// Plot data: per problem 66 positions (drawSegment, onedpath_ip.cpp:1065-1088, 33 per segment) and 4 end accelerations
+// (plotAcceleration, 1024-1027).  The launch moves 64 B of state in and 560 B out per problem: it has to be an HBM-write
+// kernel.  A 256-thread block takes 128 problems: its first 128 threads read one problem each (eight fields through the slot
+// map) and leave, per segment, the six numbers a sample is made of in LDS; then all threads write the block's 8,448 positions
+// and 512 accelerations as consecutive elements (full coalesced segments), each from the constants of its problem.  The
+// reference's divisions are multiplications by a refined reciprocal (rcp_: IEEE 1/x), one per segment instead of nine per
+// sample; the parity test allows 1e-13.  (The first form -- one thread per output element, every thread reading the eight
+// fields and dividing for itself -- ran at 0.17 of the HBM peak: it was bound by its 9 broadcast loads per wave.)
+// (Walking POSITIONS instead -- coalesced field reads, each problem's 528-byte row scattered to where prob_of says -- was measured
+// and is slower, 0.227 against 0.194 ms at 1 Mi problems: rows start on alternating 16-byte offsets, so every row ends in two
+// partial sectors.  The gather through slot_of costs eight -- with zero end velocities, which are then not read, six --
+// 32-byte sectors per problem on top of the 560 B written; that traffic is what the launch time is made of.)
+constexpr int kSampleProblems = 128;
+template <typename T, int VARIANT, bool ZV>
 __global__ void __launch_bounds__(kBlock)
 k_sample(const T *__restrict__ base, size_t stride, size_t first, size_t count, const uint32_t *__restrict__ slot_of,
          double *__restrict__ pos66, double *__restrict__ acc4)
 {
     constexpr int CB = 3 + CMap<VARIANT>::NC;
-    const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const size_t i = idx / 70;      // output row: problem first + i
-    const int slot = (int)(idx % 70);
-    if (i >= count) return;
-    const T *f = base + (slot_of ? (size_t)slot_of[first + i] : first + i);
-    const double v1 = (double)f[0], t0 = (double)f[1 * stride], t1 = (double)f[2 * stride];
-    const double p0 = (double)f[(CB + 0) * stride], v0 = (double)f[(CB + 1) * stride], p1 = (double)f[(CB + 2) * stride];
-    const double p2 = (double)f[(CB + 3) * stride], v2 = (double)f[(CB + 4) * stride];
-    if (slot < 66) {
-        const int seg = slot / 33, j = slot % 33;
-        const double x0 = seg ? p1 : p0, x1 = seg ? p2 : p1, va = seg ? v1 : v0, vb = seg ? v2 : v1, h = seg ? t1 : t0;
-        double out;
-        if (j == 0) out = x0;
-        else if (j == 32) out = x1;
-        else {
-            const double acc0 = (x1 - x0) * (6.0 / (h * h)) - (va * 4.0 + vb * 2.0) / h;
-            const double jrk0 = (vb - va) * (2.0 / (h * h)) - acc0 * (2.0 / h);
-            const double t = h * (double)j / 32.0;
-            out = x0 + (va + (acc0 + jrk0 * (t / 3.0)) * (t / 2.0)) * t;
+    __shared__ double s_seg[2][6][kSampleProblems];      // per segment: x0, x1, va, acc0, jrk0, h / 32
+    __shared__ double s_acc[4][kSampleProblems];
+    const size_t p_first = (size_t)blockIdx.x * kSampleProblems;      // output row of the block's first problem
+    const int here = (int)(count - p_first < (size_t)kSampleProblems ? count - p_first : (size_t)kSampleProblems);
+    if (threadIdx.x < here) {
+        const int q = threadIdx.x;
+        const T *f = base + (slot_of ? (size_t)slot_of[first + p_first + q] : first + p_first + q);
+        const double v1 = (double)f[0], t0 = (double)f[1 * stride], t1 = (double)f[2 * stride];
+        const double p0 = (double)f[(CB + 0) * stride], p1 = (double)f[(CB + 2) * stride], p2 = (double)f[(CB + 3) * stride];
+        const double v0 = ZV ? 0.0 : (double)f[(CB + 1) * stride], v2 = ZV ? 0.0 : (double)f[(CB + 4) * stride];
+#pragma unroll
+        for (int seg = 0; seg < 2; ++seg) {
+            const double x0 = seg ? p1 : p0, x1 = seg ? p2 : p1, va = seg ? v1 : v0, vb = seg ? v2 : v1, h = seg ? t1 : t0;
+            const double ih = rcp_<double>(h), ih2 = ih * ih;
+            const double acc0 = (x1 - x0) * (6.0 * ih2) - (va * 4.0 + vb * 2.0) * ih;
+            const double jrk0 = (vb - va) * (2.0 * ih2) - acc0 * (2.0 * ih);
+            s_seg[seg][0][q] = x0; s_seg[seg][1][q] = x1; s_seg[seg][2][q] = va;
+            s_seg[seg][3][q] = acc0; s_seg[seg][4][q] = jrk0; s_seg[seg][5][q] = h * 0.03125;
+            // end accelerations of the segment (evalAccelInit / evalAccelFinal's formulas)
+            s_acc[2 * seg][q] = ((x1 - x0) * 6.0 * ih + va * -4.0 + vb * -2.0) * ih;
+            s_acc[2 * seg + 1][q] = ((x1 - x0) * -6.0 * ih + va * 2.0 + vb * 4.0) * ih;
         }
-        pos66[i * 66 + slot] = out;
-    } else {
-        const int a = slot - 66;
-        double out;
-        if (a == 0)      out = ((p1 - p0) * 6.0 / t0 + v0 * -4.0 + v1 * -2.0) / t0;
-        else if (a == 1) out = ((p1 - p0) * -6.0 / t0 + v0 * 2.0 + v1 * 4.0) / t0;
-        else if (a == 2) out = ((p2 - p1) * 6.0 / t1 + v1 * -4.0 + v2 * -2.0) / t1;
-        else             out = ((p2 - p1) * -6.0 / t1 + v1 * 2.0 + v2 * 4.0) / t1;
-        acc4[i * 4 + a] = out;
     }
+    __syncthreads();
+    // two consecutive positions per thread and trip (a problem's 66 are 33 pairs): 16-byte nontemporal stores, 1 KiB per wave
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    auto position = [&](int q, int slot) -> double {
+        const int seg = slot >= 33, j = slot - 33 * seg;
+        if (j == 0) return s_seg[seg][0][q];
+        if (j == 32) return s_seg[seg][1][q];
+        const double t = s_seg[seg][5][q] * (double)j;      // h j / 32
+        return s_seg[seg][0][q] + (s_seg[seg][2][q] + (s_seg[seg][3][q] + s_seg[seg][4][q] * (t * (1.0 / 3.0))) * (t * 0.5)) * t;
+    };
+    v2 *out_pos = reinterpret_cast<v2 *>(pos66 + p_first * 66);      // 16-byte aligned: 66 doubles per problem, 128 problems per block
+    for (int pr = threadIdx.x; pr < here * 33; pr += kBlock) {
+        const int q = pr / 33, pair = pr - q * 33;
+        const v2 both = {position(q, 2 * pair), position(q, 2 * pair + 1)};
+        __builtin_nontemporal_store(both, out_pos + pr);
+    }
+    double *out_acc = acc4 + p_first * 4;
+    for (int o = threadIdx.x; o < here * 4; o += kBlock) out_acc[o] = s_acc[o & 3][o >> 2];
 }
 
 // printState's per-problem part for a (small) range of problems: the surrogate gap and, per constraint, what
@@ -1214,8 +1236,14 @@ hipError_t launch_move_toward_feasibility(const BatchView &b, const HostParams &
 hipError_t launch_sample_range(const BatchView &b, size_t first, size_t count, double *d_pos66, double *d_acc4, hipStream_t stream)
 {
     if (count == 0) return hipSuccess;
-    RP_DISPATCH(b, hipLaunchKernelGGL((k_sample<S, V>), dim3(grid_for(count * 70)), dim3(kBlock), 0, stream,
-                                       (const S *)b.base, b.stride, first, count, slots(b), d_pos66, d_acc4));
+    const dim3 grid((unsigned)((count + kSampleProblems - 1) / kSampleProblems));
+    if (b.zero_end_vel) {
+        RP_DISPATCH(b, hipLaunchKernelGGL((k_sample<S, V, true>), grid, dim3(kBlock), 0, stream,
+                                           (const S *)b.base, b.stride, first, count, slots(b), d_pos66, d_acc4));
+    } else {
+        RP_DISPATCH(b, hipLaunchKernelGGL((k_sample<S, V, false>), grid, dim3(kBlock), 0, stream,
+                                           (const S *)b.base, b.stride, first, count, slots(b), d_pos66, d_acc4));
+    }
     return hipGetLastError();
 }
 

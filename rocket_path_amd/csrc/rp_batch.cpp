@@ -659,6 +659,14 @@ int rp_batch_sample(rp_batch *b, double *pos66, double *acc4)
     return RP_OK;
 }
 
+int rp_batch_sample_device(rp_batch *b, double *d_pos66, double *d_acc4)
+{
+    RP_NEED_STATE(b);
+    if (!d_pos66 || !d_acc4) return fail(RP_ERR_INVALID, "null output");
+    RP_HIP(rp::launch_sample(b->view, d_pos66, d_acc4, b->stream));
+    return RP_OK;
+}
+
 int rp_batch_sample_range(rp_batch *b, size_t first, size_t count, double *pos66, double *acc4)
 {
     RP_NEED_STATE(b);

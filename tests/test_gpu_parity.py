@@ -416,6 +416,38 @@ def test_sample_against_oracle(oracle, g3):
         assert serr(pos[i], p) < 1e-13 and serr(acc[i], a) < 1e-13
 
 
+def test_sample_into_device_memory_equals_the_host_read_back():
+    import ctypes
+    rp.load_library()
+    # the HIP runtime the product library runs on (torch, if some other test imported it, brings a second copy)
+    paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}, key=lambda p: "torch" in p)
+    hip = ctypes.CDLL(paths[0])
+    n = 3 * 4096 + 17                                            # ragged last block of the kernel (128 problems per block)
+    p0, p1, p2 = rp.problems.generate(606, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as b:
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 200, 0)
+        pos, acc = b.sample()
+        d_pos, d_acc = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(d_pos), ctypes.c_size_t(n * 66 * 8)) == 0
+        assert hip.hipMalloc(ctypes.byref(d_acc), ctypes.c_size_t(n * 4 * 8)) == 0
+        try:
+            assert hip.hipMemset(d_pos, 0xff, ctypes.c_size_t(n * 66 * 8)) == 0 and hip.hipMemset(d_acc, 0xff, ctypes.c_size_t(n * 4 * 8)) == 0
+            b.sample_device(d_pos.value, d_acc.value)
+            b.sync()
+            got_pos, got_acc = np.empty((n, 66)), np.empty((n, 4))
+            assert hip.hipMemcpy(ctypes.c_void_p(got_pos.ctypes.data), d_pos, ctypes.c_size_t(n * 66 * 8), 2) == 0
+            assert hip.hipMemcpy(ctypes.c_void_p(got_acc.ctypes.data), d_acc, ctypes.c_size_t(n * 4 * 8), 2) == 0
+        finally:
+            hip.hipFree(d_pos)
+            hip.hipFree(d_acc)
+        assert np.array_equal(got_pos, pos) and np.array_equal(got_acc, acc)
+        # end points of the plot are the nodes themselves; the accelerations respect the limit at the solution
+        st = b.get_state()
+        assert np.array_equal(pos[:, 0], st[:, 11]) and np.array_equal(pos[:, 32], st[:, 13]) and np.array_equal(pos[:, 65], st[:, 14])
+        assert np.abs(acc).max() <= 100.0 * (1 + 1e-12)
+
+
 def _violating_starts(oracle, variant, n, seed, four):
     """Feasible starts pushed out of the feasible set.  four=False: 1-3 violated accelerations (durations a little
     short and/or a large midpoint velocity).  four=True: both durations much too short, so that all four end
