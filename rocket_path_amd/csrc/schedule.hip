@@ -40,6 +40,11 @@ constexpr int kThreads = 256;                 // 4 waves
 constexpr int kPerThread = 16;
 constexpr int kTileProblems = kThreads * kPerThread;      // 4,096 problems per tile
 constexpr int kKeys = 4096;                   // 64 ratio classes x 64 length levels
+#ifndef RP_SCHED_COUNT_THREADS
+#define RP_SCHED_COUNT_THREADS 256      // measured at 1 Mi problems: 256 threads 37.0 us per pass, 512: 37.1, 1,024: 36.3 -- not bound by its occupancy
+#endif
+constexpr int kCountThreads = RP_SCHED_COUNT_THREADS;      // the counting kernel's block (a tile of 4,096 problems either way)
+constexpr int kCountPerThread = kTileProblems / kCountThreads;
 constexpr int kWaves = kThreads / 64;
 constexpr int kWaveSpan = kTileProblems / kWaves;         // consecutive problems a wave owns: 1,024 = 16 groups of 64
 
@@ -61,26 +66,26 @@ __device__ __forceinline__ uint32_t schedule_key(double p0, double p1, double p2
 }
 
 template <bool RECORDS>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kCountThreads)
 k_sched_count(const double *__restrict__ pos0, const double *__restrict__ pos1, const double *__restrict__ pos2, size_t pstride,
               size_t n, uint32_t *__restrict__ hist, uint16_t *__restrict__ keys, StartRecord *__restrict__ records,
               unsigned long long *__restrict__ counters)
 {
     __shared__ uint32_t s_cnt[kKeys];
-    for (int k = threadIdx.x; k < kKeys; k += kThreads) s_cnt[k] = 0;
+    for (int k = threadIdx.x; k < kKeys; k += kCountThreads) s_cnt[k] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 128 && counters) counters[threadIdx.x] = 0;      // the batch's progress counters: a new problem set
     __syncthreads();
     const size_t first = (size_t)blockIdx.x * kTileProblems;
-    double p0[kPerThread], p1[kPerThread], p2[kPerThread];
+    double p0[kCountPerThread], p1[kCountPerThread], p2[kCountPerThread];
 #pragma unroll
-    for (int q = 0; q < kPerThread; ++q) {
-        const size_t i = first + (size_t)q * kThreads + threadIdx.x;      // any assignment of problems to threads: only the counts matter
+    for (int q = 0; q < kCountPerThread; ++q) {
+        const size_t i = first + (size_t)q * kCountThreads + threadIdx.x;      // any assignment of problems to threads: only the counts matter
         const size_t at = (i < n ? i : 0) * pstride;
         p0[q] = pos0[at]; p1[q] = pos1[at]; p2[q] = pos2[at];
     }
 #pragma unroll
-    for (int q = 0; q < kPerThread; ++q) {
-        const size_t i = first + (size_t)q * kThreads + threadIdx.x;
+    for (int q = 0; q < kCountPerThread; ++q) {
+        const size_t i = first + (size_t)q * kCountThreads + threadIdx.x;
         if (i < n) {
             const uint32_t key = schedule_key(p0[q], p1[q], p2[q]);
             atomicAdd(&s_cnt[key], 1u);
@@ -96,7 +101,7 @@ k_sched_count(const double *__restrict__ pos0, const double *__restrict__ pos1, 
     }
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * kKeys;
-    for (int k = threadIdx.x; k < kKeys; k += kThreads) row[k] = s_cnt[k];
+    for (int k = threadIdx.x; k < kKeys; k += kCountThreads) row[k] = s_cnt[k];
 }
 
 // hist[tile][key] -> exclusive prefix over the tiles, per key, in place; total[key].  A block owns 16 keys (one 64-byte
@@ -258,9 +263,9 @@ hipError_t launch_schedule(const BatchView &b, const double *d_pos0, const doubl
     uint32_t *total = (uint32_t *)((char *)d_scratch + align256((size_t)tiles * kKeys * sizeof(uint32_t)));
     uint16_t *keys = (uint16_t *)(total + kKeys);
     if (write_records)
-        hipLaunchKernelGGL((k_sched_count<true>), dim3(tiles), dim3(kThreads), 0, stream, d_pos0, d_pos1, d_pos2, pstride, b.n, hist, keys, b.records, b.counters);
+        hipLaunchKernelGGL((k_sched_count<true>), dim3(tiles), dim3(kCountThreads), 0, stream, d_pos0, d_pos1, d_pos2, pstride, b.n, hist, keys, b.records, b.counters);
     else
-        hipLaunchKernelGGL((k_sched_count<false>), dim3(tiles), dim3(kThreads), 0, stream, d_pos0, d_pos1, d_pos2, pstride, b.n, hist, keys,
+        hipLaunchKernelGGL((k_sched_count<false>), dim3(tiles), dim3(kCountThreads), 0, stream, d_pos0, d_pos1, d_pos2, pstride, b.n, hist, keys,
                            (StartRecord *)nullptr, b.counters);
     hipLaunchKernelGGL(k_sched_scan, dim3(kKeys / 16), dim3(kThreads), 0, stream, hist, tiles, total);
     hipLaunchKernelGGL(k_sched_scatter, dim3(tiles), dim3(kThreads), 0, stream, (const uint16_t *)keys, b.n, (const uint32_t *)hist,
