@@ -10,7 +10,7 @@
 //
 // Within the batch the problems lie in SCHEDULED order (schedule.hip, run when positions are set): sorted by what predicts
 // their gated step count, the segment-length ratio min|dX| / max|dX| (64 classes; similar segments take longest) and,
-// within a class, the longer segment's length (64 levels).  slot_of[] / prob_of[] map problem index <-> position; only the
+// within a class, the longer segment's length (32 levels).  slot_of[] / prob_of[] map problem index <-> position; only the
 // kernels at the ABI boundary (state in / out, read-backs by problem index) and the first kernel after set_problems look at
 // them, the Newton kernels walk positions.
 //

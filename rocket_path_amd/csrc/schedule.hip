@@ -4,14 +4,15 @@
 // runs until its slowest lane has converged, so the problems are kept grouped by what predicts their gated step count.
 // Measured on the benchmark distribution (oracle step counts of 1,048,576 problems, tests/checks/idle_lanes.py): the count
 // is a function of the segment-length ratio r = min|dX| / max|dX| (14 steps for r < 0.5 rising to 18 at r = 1) and, within a
-// ratio class, of the longer segment's length.  A 12-bit key -- 64 ratio classes x 64 length levels, 8 per octave over
-// [4, 1024), clamped outside -- leaves 1.2 % of the lane-steps idle (batch order: 19.2 %; the 32-bit key round 2 sorted on:
-// 1.0 %; 8,192 bins: 0.9 %).  A problem whose middle node lies OUTSIDE its end nodes (the path reverses; none in the
+// ratio class, of the longer segment's length.  An 11-bit key -- 64 ratio classes x 32 length levels, 4 per octave over
+// [4, 1024), clamped outside -- leaves 1.5 % of the lane-steps idle (batch order: 19.2 %; 64 levels, 4,096 keys: 1.3 %; the
+// 32-bit key round 2 sorted on: 1.0 %; 8,192 keys: 0.9 %): the pass is 5 us shorter with 2,048 keys than with 4,096 (half
+// the histogram matrix), the solve 0.5 us longer.  A problem whose middle node lies OUTSIDE its end nodes (the path reverses; none in the
 // benchmark distribution, a third of the non-monotone stress set) takes 12 steps whatever its ratio and lengths
 // (174,485 of 174,696 such problems; the rest 13), two fewer than any monotone problem: all reversals share key 0.  Without
-// that the stress set idles 12.6 % of its lane-steps, with it 1.2 % (profiles/r3_idle_lanes.log).
+// that the stress set idles 12.6 % of its lane-steps, with it 1.3 % (profiles/r3_idle_lanes.log).
 //
-// With 4,096 possible keys the order is ONE stable counting sort, three small hand-written kernels on the batch's own
+// With 2,048 possible keys the order is ONE stable counting sort, three small hand-written kernels on the batch's own
 // stream (round 2 called rocPRIM's 32-bit radix sort here: 23 dispatches and 188 us at 1 Mi problems for an order whose
 // only purpose is to save ~30 us of the solve):
 //   k_sched_count    per 4,096-problem tile: key of every problem (kept, 2 B), histogram in LDS -> hist[tile][key]; for
@@ -39,7 +40,13 @@ namespace {
 constexpr int kThreads = 256;                 // 4 waves
 constexpr int kPerThread = 16;
 constexpr int kTileProblems = kThreads * kPerThread;      // 4,096 problems per tile
-constexpr int kKeys = 4096;                   // 64 ratio classes x 64 length levels
+#ifndef RP_SCHED_LEVEL_BITS
+#define RP_SCHED_LEVEL_BITS 5                 // length levels: 5 bits = 4 per octave over [4, 1024) (6: 8 per octave, 4,096 keys -- 1.3 % idle lane-steps
+                                              // instead of 1.5 %, but a pass of 36.8 instead of 31.8 us at 1 Mi problems: profiles/r3_tuning.md)
+#endif
+constexpr int kLevelBits = RP_SCHED_LEVEL_BITS;
+constexpr int kKeyBits = 6 + kLevelBits;
+constexpr int kKeys = 1 << kKeyBits;          // 64 ratio classes x 32 length levels = 2,048 keys
 #ifndef RP_SCHED_COUNT_THREADS
 #define RP_SCHED_COUNT_THREADS 256      // measured at 1 Mi problems: 256 threads 37.0 us per pass, 512: 37.1, 1,024: 36.3 -- not bound by its occupancy
 #endif
@@ -60,9 +67,10 @@ __device__ __forceinline__ uint32_t schedule_key(double p0, double p1, double p2
     const uint32_t cls = (r >= 0.0 && r < 64.0) ? (uint32_t)r : 63u;
     const float len = (float)hi;
     int lvl = 0;
-    if (len == len && len > 0.0f) lvl = (int)(__float_as_uint(len) >> 20) - ((127 + 2) << 3);      // 8 * (log2 floor - 2) + 3 mantissa bits
-    lvl = lvl < 0 ? 0 : lvl > 63 ? 63 : lvl;
-    return (cls << 6) | (uint32_t)lvl;
+    constexpr int mant = kLevelBits - 3;      // mantissa bits in a level: 2 (4 per octave)
+    if (len == len && len > 0.0f) lvl = (int)(__float_as_uint(len) >> (23 - mant)) - ((127 + 2) << mant);      // 4 * (log2 floor - 2) + 2 mantissa bits
+    lvl = lvl < 0 ? 0 : lvl > (1 << kLevelBits) - 1 ? (1 << kLevelBits) - 1 : lvl;
+    return (cls << kLevelBits) | (uint32_t)lvl;
 }
 
 template <bool RECORDS>
@@ -152,7 +160,7 @@ __device__ __forceinline__ unsigned long long match_key(uint32_t key)
 {
     unsigned long long peers = ~0ull;
 #pragma unroll
-    for (int bit = 0; bit < 12; ++bit) {
+    for (int bit = 0; bit < kKeyBits; ++bit) {
         const bool set = (key >> bit) & 1u;
         const unsigned long long b = __ballot(set);
         peers &= set ? b : ~b;
@@ -177,7 +185,7 @@ k_sched_scatter(const uint16_t *__restrict__ keys, size_t n, const uint32_t *__r
 #pragma unroll
     for (int q = 0; q < kPerThread; ++q) {
         const size_t i = first + (size_t)q * 64 + lane;
-        key[q] = i < n ? (uint32_t)keys[i] : 0xfffu;
+        key[q] = i < n ? (uint32_t)keys[i] : (uint32_t)(kKeys - 1);
     }
 #pragma unroll
     for (int q = 0; q < kPerThread; ++q) {
@@ -187,9 +195,10 @@ k_sched_scatter(const uint16_t *__restrict__ keys, size_t n, const uint32_t *__r
 
     // base of every key = exclusive prefix of the totals (each tile recomputes it: 16 KiB from L2) + this tile's prefix
     {
-        uint32_t t[16], sum = 0;
+        constexpr int kMine = kKeys / kThreads;      // keys per thread: 16
+        uint32_t t[kMine], sum = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { t[j] = total[tid * 16 + j]; sum += t[j]; }
+        for (int j = 0; j < kMine; ++j) { t[j] = total[tid * kMine + j]; sum += t[j]; }
         // exclusive prefix of the 256 partial sums: inside the wave by shuffles, across the four waves through LDS
         uint32_t incl = sum;
 #pragma unroll
@@ -201,10 +210,10 @@ k_sched_scatter(const uint16_t *__restrict__ keys, size_t n, const uint32_t *__r
         __syncthreads();                               // also: every wave's counts are in s_wave
         uint32_t run = incl - sum;
         for (int j = 0; j < w; ++j) run += s_part[j];
-        const uint32_t *row = hist + (size_t)blockIdx.x * kKeys + tid * 16;
+        const uint32_t *row = hist + (size_t)blockIdx.x * kKeys + tid * kMine;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int k = tid * 16 + j;
+        for (int j = 0; j < kMine; ++j) {
+            const int k = tid * kMine + j;
             s_off[k] = run + row[j];
             run += t[j];
             // per-wave counts -> exclusive prefix over the waves (in place, both halves of the word at once)
@@ -222,7 +231,7 @@ k_sched_scatter(const uint16_t *__restrict__ keys, size_t n, const uint32_t *__r
     for (int q = 0; q < kPerThread; ++q) {
         const size_t i = first + (size_t)q * 64 + lane;
         const bool live = i < n;
-        const uint32_t k = live ? key[q] : 0xfffu;      // dead lanes only ever sit behind live ones (the tail of the batch)
+        const uint32_t k = live ? key[q] : (uint32_t)(kKeys - 1);      // dead lanes only ever sit behind live ones (the tail of the batch)
         unsigned long long peers = match_key(k) & __ballot(live);
         const unsigned long long below = peers & ((1ull << lane) - 1ull);
         const int rank = __popcll(below);

@@ -41,9 +41,11 @@ cls = np.where((ratio * 64 >= 0) & (ratio * 64 < 64), np.floor(ratio * 64), 63).
 bits = hi.astype(np.float32).view(np.uint32).astype(np.uint64) >> np.uint64(5)
 round2 = np.argsort((cls << np.uint64(26)) | bits, kind="stable")
 print("round 2: 32-bit key (ratio class, length)      idle %.4f" % idle(round2))
-lvl = np.clip((hi.astype(np.float32).view(np.uint32).astype(np.int64) >> 20) - ((127 + 2) << 3), 0, 63)
-shipped = np.argsort((cls.astype(np.int64) << 6) | lvl, kind="stable")
-print("schedule.hip: 12-bit key (64 classes x 64 lvls) idle %.4f" % idle(shipped))
+lvl64 = np.clip((hi.astype(np.float32).view(np.uint32).astype(np.int64) >> 20) - ((127 + 2) << 3), 0, 63)
+print("12-bit key (64 classes x 64 levels)            idle %.4f" % idle(np.argsort((cls.astype(np.int64) << 6) | lvl64, kind="stable")))
+lvl = np.clip((hi.astype(np.float32).view(np.uint32).astype(np.int64) >> 21) - ((127 + 2) << 2), 0, 31)
+shipped = np.argsort((cls.astype(np.int64) << 5) | lvl, kind="stable")
+print("schedule.hip: 11-bit key (64 classes x 32 lvls) idle %.4f" % idle(shipped))
 x = steps[shipped].reshape(-1, 64)
 print("   step counts inside a chunk differ by %.2f on average; chunk maxima %d .. %d" % ((x.max(axis=1) - x.min(axis=1)).mean(), x.max(axis=1).min(), x.max(axis=1).max()))
 print("sorted by the step count itself (bound)        idle %.6f" % idle(np.argsort(steps, kind="stable")))
@@ -58,8 +60,8 @@ for dist, name in ((rp.problems.DIST_MONOTONE, "monotone"), (rp.problems.DIST_RE
     d0, d1 = np.abs(p1 - p0), np.abs(p2 - p1)
     lo, hi = np.minimum(d0, d1), np.maximum(d0, d1)
     cls = np.minimum(np.floor(lo / hi * 64), 63).astype(np.int64)
-    lvl = np.clip((hi.astype(np.float32).view(np.uint32).astype(np.int64) >> 20) - ((127 + 2) << 3), 0, 63)
+    lvl = np.clip((hi.astype(np.float32).view(np.uint32).astype(np.int64) >> 21) - ((127 + 2) << 2), 0, 31)
     rev = (p1 - p0) * (p2 - p1) < 0
     print("%-15s reversals %6d (their steps: %s)   idle: problem order %.4f, classes x levels only %.4f, reversals -> key 0 (shipped) %.4f"
-          % (name, rev.sum(), np.unique(steps[rev]).tolist(), idle(np.arange(N)), idle(np.argsort((cls << 6) | lvl, kind="stable")),
-             idle(np.argsort(np.where(rev, 0, (cls << 6) | lvl), kind="stable"))))
+          % (name, rev.sum(), np.unique(steps[rev]).tolist(), idle(np.arange(N)), idle(np.argsort((cls << 5) | lvl, kind="stable")),
+             idle(np.argsort(np.where(rev, 0, (cls << 5) | lvl), kind="stable"))))

@@ -340,7 +340,7 @@ def test_two_rank_bench_rehearsal_on_one_device_covers_the_whole_batch(ranks):
 # ---- the scheduled order inside the batch (csrc/schedule.hip): invisible at the boundary ----
 
 def _schedule_key(p0, p1, p2):
-    """schedule.hip's key: ratio class (6 bits) : length level (6 bits: 8 per octave of the longer segment's length from 4 up);
+    """schedule.hip's key: ratio class (6 bits) : length level (5 bits: 4 per octave of the longer segment's length from 4 up);
     0 for a path that reverses."""
     d0, d1 = np.abs(p1 - p0), np.abs(p2 - p1)
     lo, hi = np.minimum(d0, d1), np.maximum(d0, d1)
@@ -348,11 +348,11 @@ def _schedule_key(p0, p1, p2):
         r = lo / hi * 64.0
     cls = np.where((r >= 0.0) & (r < 64.0), np.floor(r), 63).astype(np.int64)
     length = hi.astype(np.float32)
-    lvl = (length.view(np.uint32).astype(np.int64) >> 20) - ((127 + 2) << 3)
+    lvl = (length.view(np.uint32).astype(np.int64) >> 21) - ((127 + 2) << 2)
     lvl = np.where((length == length) & (length > 0), lvl, 0)
     with np.errstate(invalid="ignore", over="ignore"):
         reverses = (p1 - p0) * (p2 - p1) < 0.0
-    return np.where(reverses, 0, (cls << 6) | np.clip(lvl, 0, 63))
+    return np.where(reverses, 0, (cls << 5) | np.clip(lvl, 0, 31))
 
 
 @pytest.mark.parametrize("n,dist", [(1, 2), (63, 2), (4096, 2), (3 * 4096 + 77, 2), (40 * 4096 + 1, 0), (9000, 1)])
