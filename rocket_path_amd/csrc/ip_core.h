@@ -86,12 +86,12 @@ template <> __device__ __forceinline__ float rcp_<float>(float x) { return 1.0f 
 #else
 template <> __device__ __forceinline__ double rcp_<double>(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-#ifndef RP_RCP_ONE_STEP      // A/B knob: one refinement only (<= 10 ulp instead of IEEE 1/x)
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-#endif
-    return r;
+    // v_rcp_f64 is good to 2^-24 (4.6e-8 measured); ONE cubic refinement, r (1 + e + e^2) with e = 1 - x r, leaves e^3 ~ 1e-22:
+    // three multiply-adds, bit-equal to IEEE 1/x on 4.19 M samples (profiles/probes/rcp_probe.hip), as two Newton steps -- four
+    // multiply-adds, what this was until late in round 3 -- are.  (One Newton step, 10 ulp, fails parity: profiles/r3_tuning.md.)
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
 template <> __device__ __forceinline__ float rcp_<float>(float x)
 {
@@ -100,9 +100,9 @@ template <> __device__ __forceinline__ float rcp_<float>(float x)
     return r;
 }
 #endif
-// One refinement: <= 10 ulp (measured on gfx950: raw v_rcp_f64 is 2^-24, one Newton step 2.2e-15, two
-// steps bit-equal to IEEE 1/x on 4M samples -- profiles/probes/rcp_probe.hip).  Used only where the
-// quotient feeds a bound, not the iterate: the fraction-to-boundary ratios.
+// One Newton refinement: <= 10 ulp (measured on gfx950: raw v_rcp_f64 is 2^-24, one Newton step 2.2e-15 --
+// profiles/probes/rcp_probe.hip).  Used only where the quotient feeds a bound, not the iterate: the
+// fraction-to-boundary ratios.
 template <typename T> __device__ __forceinline__ T rcp1_(T x);
 #ifdef RP_EXACT_DIV
 template <> __device__ __forceinline__ double rcp1_<double>(double x) { return 1.0 / x; }
