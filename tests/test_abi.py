@@ -129,7 +129,9 @@ def test_bench_refuses_to_run_without_a_gpu():
     out = r.stderr + r.stdout
     assert r.returncode != 0
     assert "starting 2 ranks" in out and "torch.distributed.run" in out
-    assert out.count("no HIP device") >= 2          # both children got as far as looking for their GPU
+    # the children got as far as looking for their GPU (the elastic agent tears the other rank down as soon as the first one has
+    # failed, so the second message is not guaranteed: 1 in ~4 runs of this test saw only one)
+    assert out.count("no HIP device") >= 1
     assert "{\"metric\"" not in r.stdout
 
 
