@@ -1390,12 +1390,14 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 
 // ---- the same step IN PLACE, for the gated solve ----------------------------------------------------------------------
 // newton_step_to keeps the point and multipliers a step starts from next to the trial it is evaluating (a rejected trial is
-// followed by another from the same start), so an accepted trial has to be MOVED into the registers the next step reads: 11
-// 64-bit moves per step on a kernel that is bound by vector-instruction issue.  Here the trial overwrites the state (a
-// multiply-add onto itself) and the start of the step waits in LDS instead -- 11 ds_write per step, which issue on the
-// LDS port beside the other waves' arithmetic -- to be read back only when a trial is rejected (one step in five has a
-// rejected feasibility trial, a rejected residual trial is rare before convergence).  Same functions, same operands, same
-// order of decisions as newton_step_to<MEMO = false, MU = 0>: every bit of every iterate is the same.
+// followed by another from the same start), and its loops are left by every lane when that lane is done -- for which the
+// compiler copies every value that is live after such a loop once per trip, for the lanes that have left: 11 + 9 64-bit moves
+// per step on a kernel that is bound by vector-instruction issue (and, back to back, by the energy of a step).  Here the trial
+// overwrites the state (a multiply-add onto itself), the start of the step waits in LDS instead -- 11 ds_write per step, which
+// issue on the LDS port beside the other waves' arithmetic -- to be read back only when a trial is rejected (one step in five
+// has a rejected feasibility trial, a rejected residual trial is rare before convergence), and the loops run while ANY lane of
+// the wave is inside (wave-uniform exits: nothing to copy).  Same functions, same operands, same order of decisions as
+// newton_step_to<MEMO = false, MU = 0>: every bit of every iterate is the same (tests/checks/inplace_ab.py, 36 cases).
 // bk: this lane's column of the block's backup area, field q at bk[q * 64]; volatile so that the compiler neither forwards the
 // stored values to the reads (keeping them in registers is what this form is there to avoid) nor drops the stores.
 // The loops are written with the trial formed where s is set (at the bottom, from the backed-up start), so that a trial
