@@ -881,6 +881,61 @@ struct HalvingDiag {
 #define RP_FEAS_RAY 1         // ... first in closed form along the ray (0: trial by trial only)
 #endif
 
+// The feasibility loop's certain halvings (F4): s is walked past every trial that is infeasible beyond doubt -- first along the
+// ray in closed form (ray_proof), then trial by trial (infeasible_beyond_doubt) -- and the number of halvings made is returned;
+// the caller's loop takes over at the first trial that needs a proper look.  Wave-uniform loops.
+template <typename T, int VARIANT, class P, class D>
+__device__ __forceinline__ int skip_certain_halvings(const P &k, const KParams<T> &kp, T L, T v, T t0, T t1, T dxv, T dx0, T dx1, T &s, D &diag)
+{
+    int it_feas = 0;
+    // (not in the one instantiation that has no registers for it -- double precision with non-zero end velocities, 167 of the 168
+    // three waves allow: the proof changes no decision, so leaving it out there changes no result either)
+    if constexpr (VARIANT == 4 && RP_FEAS_SCREEN && (P::zero_vel || sizeof(T) == 4)) {
+        // the halvings whose trial misses the limits beyond doubt: the reference evaluates them, finds an error > 0 and halves; this
+        // halves.  Wave-uniform loops, every lane to its first trial that needs a proper look: first along the ray in closed form
+        // for the one limit that stays broken longest (ray_proof), then trial by trial for all four (infeasible_beyond_doubt).
+        if constexpr (RP_FEAS_RAY && !P::lean) {
+            const RayProof<T> ray = ray_proof<T, P>(k, L, v, t0, t1, dxv, dx0, dx1, s);
+            if (kp.backtrack == T(0.5)) {
+                // The number of proven halvings by bisection, no loop over them.  g is a quadratic with g(0) <= 0 wherever x itself is
+                // not beyond doubt infeasible: if g(s) > 0 at the first trial, g > 0 exactly on the trials down to a root and <= 0 below
+                // it (convex: g increases beyond its one positive root; concave: g >= the smaller of two positive values in
+                // between), so "g(s 2^-k) > 0" is true up to some k and false from there on.  Seven probes find the last true k in
+                // [0, 127]; every counted halving lies between two EVALUATED positives.  (g(0) > 0: all 127 hold, the budget caps it.)
+                int last = 0;
+#pragma unroll
+                for (int b = 64; b >= 1; b >>= 1) last += ray.holds(ldexp_(s, -(last + b))) ? b : 0;
+                int proven = (ray.on && ray.holds(s)) ? last + 1 : 0;
+                proven = proven < kp.max_bt ? proven : kp.max_bt;
+                s = ldexp_(s, -proven);
+                it_feas = proven;
+                if constexpr (!std::is_same<D, NoDiag>::value)
+                    for (int q = 0; q < proven; ++q) diag.feas();
+            } else {
+                bool more = ray.on;
+                while (__builtin_amdgcn_ballot_w64(more) != 0ull) {      // (branch-free body: two multiply-adds, a compare, the selects)
+                    more = more && it_feas < kp.max_bt && ray.holds(s);
+                    s *= more ? kp.backtrack : T(1);
+                    it_feas += more ? 1 : 0;
+                    if (more) diag.feas();
+                }
+            }
+        }
+        bool more = true;
+        do {
+            if (more) {
+                more = it_feas < kp.max_bt && infeasible_beyond_doubt<T, P>(k, L, fma_(dxv, s, v), fma_(dx0, s, t0), fma_(dx1, s, t1));
+                if (more) {
+                    s *= kp.backtrack;
+                    ++it_feas;
+                    diag.feas();
+                }
+            }
+        } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
+    }
+    return it_feas;
+}
+
 // ---- one Newton step -------------------------------------------------------------------
 // In:  x = (v, t0, t1), lam, c = reciprocals + accelerations at x, gap = surrogate duality gap at x.
 // Out: the same at the new point (the caller recomputes the gap from c).
@@ -993,52 +1048,7 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
     Acc<T> et;                 // evaluation at the current trial point
     T tv = v, tt0 = t0, tt1 = t1;
     bool et_valid = false;     // et holds the accelerations of (tv,tt0,tt1) == x + s*dx
-    int it_feas = 0;
-    // (not in the one instantiation that has no registers for it -- double precision with non-zero end velocities, 167 of the 168
-    // three waves allow: the proof changes no decision, so leaving it out there changes no result either)
-    if constexpr (VARIANT == 4 && RP_FEAS_SCREEN && (P::zero_vel || sizeof(T) == 4)) {
-        // the halvings whose trial misses the limits beyond doubt: the reference evaluates them, finds an error > 0 and halves; this
-        // halves.  Wave-uniform loops, every lane to its first trial that needs a proper look: first along the ray in closed form
-        // for the one limit that stays broken longest (ray_proof), then trial by trial for all four (infeasible_beyond_doubt).
-        if constexpr (RP_FEAS_RAY && !P::lean) {
-            const RayProof<T> ray = ray_proof<T, P>(k, L, v, t0, t1, dxv, dx0, dx1, s);
-            if (kp.backtrack == T(0.5)) {
-                // The number of proven halvings by bisection, no loop over them.  g is a quadratic with g(0) <= 0 wherever x itself is
-                // not beyond doubt infeasible: if g(s) > 0 at the first trial, g > 0 exactly on the trials down to a root and <= 0 below
-                // it (convex: g increases beyond its one positive root; concave: g >= the smaller of two positive values in
-                // between), so "g(s 2^-k) > 0" is true up to some k and false from there on.  Seven probes find the last true k in
-                // [0, 127]; every counted halving lies between two EVALUATED positives.  (g(0) > 0: all 127 hold, the budget caps it.)
-                int last = 0;
-#pragma unroll
-                for (int b = 64; b >= 1; b >>= 1) last += ray.holds(ldexp_(s, -(last + b))) ? b : 0;
-                int proven = (ray.on && ray.holds(s)) ? last + 1 : 0;
-                proven = proven < kp.max_bt ? proven : kp.max_bt;
-                s = ldexp_(s, -proven);
-                it_feas = proven;
-                if constexpr (!std::is_same<D, NoDiag>::value)
-                    for (int q = 0; q < proven; ++q) diag.feas();
-            } else {
-                bool more = ray.on;
-                while (__builtin_amdgcn_ballot_w64(more) != 0ull) {      // (branch-free body: two multiply-adds, a compare, the selects)
-                    more = more && it_feas < kp.max_bt && ray.holds(s);
-                    s *= more ? kp.backtrack : T(1);
-                    it_feas += more ? 1 : 0;
-                    if (more) diag.feas();
-                }
-            }
-        }
-        bool more = true;
-        do {
-            if (more) {
-                more = it_feas < kp.max_bt && infeasible_beyond_doubt<T, P>(k, L, fma_(dxv, s, v), fma_(dx0, s, t0), fma_(dx1, s, t1));
-                if (more) {
-                    s *= kp.backtrack;
-                    ++it_feas;
-                    diag.feas();
-                }
-            }
-        } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
-    }
+    const int it_feas = skip_certain_halvings<T, VARIANT, P, D>(k, kp, L, v, t0, t1, dxv, dx0, dx1, s, diag);
     for (int it = it_feas; it < kp.max_bt; ++it) {
         tv = fma_(dxv, s, v);
         tt0 = fma_(dx0, s, t0);
@@ -1435,12 +1445,14 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
     // -- backtrack until primal feasible (onedpath_ip.cpp:919-928); a trial is formed where s is set --
     Acc<T> et;
     T u0, u1;      // dX / t of the trial point et belongs to
+    NoDiag none;
+    const int it_feas = skip_certain_halvings<T, VARIANT, P, NoDiag>(k, kp, L, v, t0, t1, dxv, dx0, dx1, s, none);      // (F4: its certain halvings)
     v = fma_(dxv, s, v);
     t0 = fma_(dx0, s, t0);
     t1 = fma_(dx1, s, t1);
     {
         bool open = true;
-        int it = 0;
+        int it = it_feas;
         do {
             if (open) {
                 accel_values_u(k, v, t0, t1, et, u0, u1);

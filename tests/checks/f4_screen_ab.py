@@ -39,5 +39,19 @@ for dist in (0, 1, 2):
         for _ in range(30):
             a.step(1)
         out["dist%d_nzv_single" % dist] = a.get_state()
+# the gated kernel's in-place step makes the same walk: F4 solves (they stall; the stall detector stops them) and gated rounds
+for dist in (0, 2):
+    p0, p1, p2 = rp.problems.generate(5150 + dist, 0, n, dist)
+    for dtype in (rp.DTYPE_F64, rp.DTYPE_F32_STATE, rp.DTYPE_F32):
+        with rp.Batch(n, rp.VARIANT_F4, dtype) as a:
+            a.set_problems(p0, p1, p2)
+            a.solve(1e-6, 40, 0)
+            out["gated_dist%d_d%d_solve40" % (dist, dtype)] = a.get_state()
+            out["gated_dist%d_d%d_iters" % (dist, dtype)], out["gated_dist%d_d%d_status" % (dist, dtype)] = a.get_iters()
+            a.set_params(stall_window=8)
+            a.set_problems(p0, p1, p2)
+            a.solve(1e-6, 200, 0)
+            out["gated_dist%d_d%d_stall" % (dist, dtype)] = a.get_state()
+            out["gated_dist%d_d%d_stall_iters" % (dist, dtype)], out["gated_dist%d_d%d_stall_status" % (dist, dtype)] = a.get_iters()
 np.savez(sys.argv[2], **out)
 print("wrote", sys.argv[2], len(out), "arrays")
