@@ -52,7 +52,28 @@ B_MOVED_F4_F32_ZV = 68.0
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_PEAK_TFLOPS = 78.6   # fp64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 FP32_PEAK_TFLOPS = 157.3  # fp32 vector peak, same guide
-PROFILE_TAG = "r3"        # profiles/<tag>_*.json hold the rocprofv3 counter summaries the file-sourced numbers come from
+PROFILE_TAG = "r4"        # profiles/<tag>_*.json hold the rocprofv3 counter summaries the file-sourced numbers come from
+KERNEL_SOURCES = ("rocket_path_amd/csrc/ip_core.h", "rocket_path_amd/csrc/ip_kernels.hip", "rocket_path_amd/csrc/feas_core.h")
+
+
+def source_hashes():
+    import hashlib
+    return {f: hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest()[:16] for f in KERNEL_SOURCES}
+
+
+def profile_provenance():
+    """Which commit and which kernel sources the file-sourced counter numbers were collected from (profiles/<tag>_sources.json,
+    written by profiles/summarize.py at collection time), and whether the kernel sources are still those: a kernel change
+    without a re-collection must not silently mis-price a roofline fraction."""
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_sources.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return {"file": None, "current": False, "note": "no profiles/%s_sources.json: counter-derived fractions withheld" % PROFILE_TAG}
+    now = source_hashes()
+    changed = [f for f in KERNEL_SOURCES if rec.get("sha256_16", {}).get(f) != now[f]]
+    return {"file": "profiles/%s_sources.json" % PROFILE_TAG, "collected_at_commit": rec.get("commit"), "current": not changed,
+            "changed_since_collection": changed}
 
 
 def profile_number(fname, *keys):
@@ -178,6 +199,9 @@ def main():
     ap.add_argument("--pipelined", action="store_true",
                     help="also time the end-to-end path with the batches dealt alternately onto two streams (overlapping kernels: "
                          "not part of the default run, whose rocprofv3 kernel statistics must stay per-kernel clean)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="with --gpus 1: still create the torch.distributed process group on the nccl (= RCCL) backend and run the "
+                         "summary all-reduce through it on the device tensor -- the N > 1 code path end to end on the one GPU there is")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: run the N-rank code path with every rank on device 0 and gloo for the collectives "
                          "(RCCL refuses two ranks on one GPU); numbers from such a run are not benchmark results")
@@ -204,8 +228,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
-    if world > 1:
+    grouped = world > 1 or args.force_process_group      # a process group exists and every collective below goes through it
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -240,15 +268,15 @@ def main():
     summary = torch.zeros(4, dtype=torch.float64, device=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
     # ---- warmup: W untimed passes ----
     for i in range(W):
         pass_(i)
-    if world > 1:
-        sharding.allreduce_summary(summary.clone().to(coll_dev))     # RCCL communicator setup outside the timed region
+    if grouped:
+        sharding.allreduce_summary(summary.clone().to(coll_dev), force=True)     # RCCL communicator setup outside the timed region
     barrier()
 
     # ---- timed: exactly K passes, then the final summary reduction (+ all-reduce) ----
@@ -263,7 +291,7 @@ def main():
     lead.event_record(1)
     last.reduce_device(summary.data_ptr())
     lead.sync()
-    summary = sharding.allreduce_summary(summary.to(coll_dev))
+    summary = sharding.allreduce_summary(summary.to(coll_dev), force=grouped)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -274,7 +302,7 @@ def main():
     steps_local = one["total_steps"] * K
     conv_local = one["n_converged"] * K
     t = torch.tensor([elapsed, steps_local, conv_local], dtype=torch.float64, device=coll_dev)
-    if world > 1:
+    if grouped:
         tm = t[:1].clone()
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ts = t[1:].clone()
@@ -285,13 +313,15 @@ def main():
     g = sharding.summary_dict(summary)
 
     if rank != 0:
-        if world > 1:
+        if grouped:
             dist.barrier()
             dist.destroy_process_group()
         return
 
     steps_per_launch = steps_local / max(K, 1)
     alg_gbs = B_ALG_F3 * steps_per_launch / (kernel_ms * 1e-3) / 1e9
+    prov = profile_provenance()
+    fresh = prov["current"]      # the kernel sources are the ones the committed counters were collected from
     traffic, traffic_src = profile_number(PROFILE_TAG + "_hbm_traffic.json", "k_solve_chunks_f3_f64", "hbm_bytes_per_launch")
     flop_per_step, flop_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_flop_per_gated_newton_step")      # the gated kernel itself
     if flop_per_step is None:
@@ -302,7 +332,7 @@ def main():
     winsts, winsts_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_valu_wave_insts_per_gated_launch")
     VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4      # G wave-instructions/s at the fp64 rate
     valu_issue = None
-    if winsts is not None and abs(count - N_PER_GPU) == 0:
+    if winsts is not None and abs(count - N_PER_GPU) == 0 and fresh:
         valu_issue = {"achieved": winsts / (kernel_ms * 1e-3) / 1e9, "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instructions/s",
                       "frac": winsts / (kernel_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_G,
                       "valu_wave_instructions_per_launch": winsts, "source": winsts_src,
@@ -314,7 +344,8 @@ def main():
         "value": steps_all / elapsed,
         "unit": "Newton steps/s",
         "n_gpus": world,
-        "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,      # what RCCL (torch.distributed "nccl") saw
+        "ranks_in_process_group": dist.get_world_size() if grouped else 1,      # what RCCL (torch.distributed "nccl") saw
+        "process_group_backend": (dist.get_backend() if grouped else None),    # "nccl" = RCCL; None: no group was created (N = 1 without --force-process-group)
         "self_launched": bool(os.environ.get("RP_BENCH_SELF_LAUNCHED")),
         "steps": K,
         "warmup": W,
@@ -344,11 +375,11 @@ def main():
         # rocprofv3 SQ counters (2 x FMA + MUL + ADD + TRANS wave-instructions of an all-lanes-active launch, per lane-step).
         "roofline": {
             "bound": "fp64_valu", "kernel": "k_solve_chunks<double, double, F3> (fused gated solve, one 64-problem chunk of the scheduled order per wave)",
-            "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
-            "flop_per_newton_step": flop_per_step, "flop_per_newton_step_source": flop_src,
+            "achieved": tflops if fresh else None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS if fresh else None,
+            "flop_per_newton_step": flop_per_step, "flop_per_newton_step_source": flop_src, "counters_provenance": prov,
             "avg_launch_ms": kernel_ms, "sustained_ms_per_launch": sustained_ms, "newton_steps_per_launch": steps_per_launch,
             "sustained_newton_steps_per_s": steps_per_launch / (sustained_ms * 1e-3),
-            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic": traffic if fresh else None, "traffic_source": traffic_src,
             "note": "flop actually executed by the timed kernel (SQ counters of the same kernel on identical problems, per lane-step); "
                     "idle lane-steps of the gated solve (~1 % in the scheduled order) are not counted; traffic = HBM bytes per launch from FETCH_SIZE (x2, "
                     "calibrated) + WRITE_SIZE: each state crosses HBM once per solve.  sustained_ms_per_launch = the second half of the K "
@@ -392,6 +423,44 @@ def main():
         lead.sync()
         ms = lead.event_elapsed_ms(2, 3) / len(use)
         chk = use[-1].reduce()
+        # ... and with the answers where a caller can use them: in PROBLEM order, in device memory (the batch keeps its problems in
+        # scheduled order; in the reference the answer of problem i is var[] of trajectory i, onedpath_ip.cpp:47-52).  Two forms:
+        # (a) a solution buffer bound to the batch -- the solve itself writes each problem's 32-byte record as the problem leaves it;
+        # (b) a separate pass after the solve (rp_batch_solution_device: walks positions, scatters whole sectors).
+        sol = torch.empty((count, 4), dtype=torch.float64, device=torch.device("cuda", local_rank))      # n x 32 B
+        for b in use:
+            b.bind_solution(sol.data_ptr())
+        use[0].set_problems_device(*ptrs)
+        use[0].solve(GAP_TOL, MAX_ITER, 0)
+        lead.sync()
+        lead.event_record(2)
+        for b in use:
+            b.set_problems_device(*ptrs)
+            b.solve(GAP_TOL, MAX_ITER, 0)
+        lead.event_record(3)
+        lead.sync()
+        ms_bound = lead.event_elapsed_ms(2, 3) / len(use)
+        rec_bound = sol.clone()
+        for b in use:
+            b.bind_solution(None)
+        sol.zero_()
+        lead.event_record(2)
+        for b in use:
+            b.set_problems_device(*ptrs)
+            b.solve(GAP_TOL, MAX_ITER, 0)
+            b.solution_device(sol.data_ptr())
+        lead.event_record(3)
+        lead.sync()
+        ms_gather = lead.event_elapsed_ms(2, 3) / len(use)
+        lead.event_record(2)
+        for b in use:
+            b.solution_device(sol.data_ptr())
+        lead.event_record(3)
+        lead.sync()
+        ms_gather_alone = lead.event_elapsed_ms(2, 3) / len(use)
+        same_records = bool(torch.equal(rec_bound.view(torch.int64), sol.view(torch.int64)))
+        steps_in_records = int(sol.view(torch.int32)[:, 6].sum().item())      # the iteration counts of the records (word 6 of 8)
+        del sol, rec_bound
         # The same work with the batches dealt alternately onto TWO streams: batch i + 1's scheduling pass (three small,
         # latency-bound kernels) and the start of its solve run under the drain of batch i's solve.  A throughput figure for a
         # caller that pipelines independent batches; wall-clock timed (events of one stream do not span two).
@@ -426,6 +495,16 @@ def main():
                             "k_sched_count / k_sched_scan / k_sched_scatter) + the fused gated solve starting from the feasible start "
                             "formed in registers (k_solve_chunks<START>); nothing precomputed, no host synchronisation in between" % count,
                 "batches": len(use), "ms_per_batch": ms, "newton_steps_per_s": chk["total_steps"] / (ms * 1e-3),
+                "with_solutions_in_problem_order": {
+                    "workload": "the same, ending with every problem's rp_solution record (vel1, duration0, duration1, iters, status: 32 B) "
+                                "in PROBLEM order in device memory",
+                    "bound_buffer": {"ms_per_batch": ms_bound, "newton_steps_per_s": chk["total_steps"] / (ms_bound * 1e-3),
+                                     "note": "rp_batch_bind_solution: k_solve_chunks writes each record itself (one scattered sector per problem)"},
+                    "separate_pass": {"ms_per_batch": ms_gather, "newton_steps_per_s": chk["total_steps"] / (ms_gather * 1e-3),
+                                      "solution_pass_alone_ms": ms_gather_alone,
+                                      "solution_pass_GBps_on_68_B_per_problem": 68.0 * count / (ms_gather_alone * 1e-3) / 1e9,
+                                      "note": "rp_batch_solution_device after the solve (k_solution: 32 B read coalesced + 4 B map + one 32 B sector written per problem)"},
+                    "both_forms_bitwise_equal": same_records, "steps_summed_from_the_records": steps_in_records},
                 "set_problems_device_ms": sched_ms, "schedule_fraction_of_batch": sched_ms / ms,
                 "newton_steps_per_batch": chk["total_steps"], "converged_fraction": chk["n_converged"] / count,
                 "headline_for_comparison_ms": kernel_ms, "pipelined_over_two_streams": two,
@@ -459,10 +538,8 @@ def main():
 
         reinit()
         ms_cold = sweep(lambda b: b.step(1))
-        os.environ["RP_STREAM_PROBE"] = "1"
         reinit()
-        ms_probe = sweep(lambda b: b.step(0))
-        del os.environ["RP_STREAM_PROBE"]
+        ms_probe = sweep(lambda b: b.traffic_probe())
         lead.set_problems_device(*ptrs)
         lead.restart()
         lead.step(1)
@@ -557,7 +634,7 @@ def main():
                                    "traffic": k1_traffic, "traffic_source": k1_src,
                                    "note": "68 B move per step (10 floats read, 7 written); SURVEY 8d's algorithmic 76 B gives %.0f GB/s" % (
                                        B_ALG_F4_F32 * count / (t1 * 1e-3) / 1e9)}}
-            if flop is not None:
+            if flop is not None and fresh:
                 tf = flop * count * 50 / (t50 * 1e-3) / 1e12
                 out["fused_roofline"] = {"bound": "fp64_valu" if peak_tflops == FP64_PEAK_TFLOPS else "fp32_valu", "achieved": tf,
                                          "peak": peak_tflops, "unit": "TFLOP/s", "frac": tf / peak_tflops,
@@ -606,6 +683,19 @@ def main():
                 c7.sync()
                 ms.append(c7.event_elapsed_ms(4, 5))
             t_f = min(ms[1:])
+        def feas_roofline(ms_f, nprob):
+            fl, fl_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_flop_per_feasibility_move_4_rows")
+            vi, _ = profile_number(PROFILE_TAG + "_sq_counters.json", "_valu_insts_per_feasibility_move_4_rows")
+            if fl is None or not fresh:
+                return None
+            tf = fl * nprob / (ms_f * 1e-3) / 1e12
+            return {"bound": "fp64_valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                    "flop_per_problem": fl, "valu_instructions_per_problem": vi, "source": fl_src,
+                    "valu_issue_frac": (vi * nprob / 64.0 / (ms_f * 1e-3) / 1e9 / (256 * 4 * 2.4 / 4)) if vi else None,
+                    "note": "SQ counters of k_move_toward_feasibility on 1 Mi starts with four violated rows each (IEEE divisions and square roots "
+                            "in Eigen's order: 11-instruction division sequences, few of them multiply-adds): the launch is issue-bound, "
+                            "not traffic-bound"}
+
         line["neighbours"] = {
             "workload": "SURVEY 8f rows 1 and 3: plot data of %d solved problems into device memory (k_sample); feasibility move of %d infeasible "
                         "starts (k_feasibility_move: four violated rows each, the rank-deficient branch of the QR)" % (count, n7),
@@ -617,6 +707,7 @@ def main():
                                             "same launch is %.0f GB/s" % (756.0 * count / (t_s * 1e-3) / 1e9)}},
             "feasibility_move": {"ms": t_f, "problems_per_s": n7 / (t_f * 1e-3),
                                  "hbm_GBps_on_136_B_per_problem": 136.0 * n7 / (t_f * 1e-3) / 1e9,
+                                 "roofline": feas_roofline(t_f, n7),
                                  "note": "16 fields read, 3 written per problem; the arithmetic (Gram matrix, Eigen-ordered 4 x 4 column-pivoted "
                                          "Householder QR in double precision, one problem per lane) is what the launch time is made of"}}
 
@@ -627,7 +718,7 @@ def main():
 
     print(json.dumps(line))
     sys.stdout.flush()
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

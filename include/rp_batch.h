@@ -43,8 +43,10 @@ typedef struct rp_batch rp_batch; /* opaque, owned by the caller between create 
  * (rocket_path_amd/capi.py and BatchedOneDPathIP do) -- rp_params grew in revision 2 (mu_mode, mu_sigma_try), and a caller
  * compiled against the older header would have handed rp_batch_set_params a shorter struct.
  *   1  round 1      2  round 2: rp_params + mu_mode / mu_sigma_try; rp_batch_field_ptr returns batch order (rp_batch_slot_map)
- *   3  round 3: sizeof(rp_params) returned by rp_params_size(); set_problems defers the feasible start (no visible change) */
-#define RP_ABI_VERSION 3
+ *   3  round 3: sizeof(rp_params) returned by rp_params_size(); set_problems defers the feasible start
+ *   4  round 4: rp_solution records (rp_batch_solution_device, rp_batch_bind_solution); rp_batch_traffic_probe replaces an
+ *      environment switch; the library reads nothing from the environment; rp_batch_sample_device checks its alignment */
+#define RP_ABI_VERSION 4
 
 typedef enum {
     RP_OK = 0,
@@ -105,6 +107,14 @@ typedef struct {
     double total_steps;     /* Newton steps executed since the last init/set_state */
 } rp_reduction;
 
+/* One problem's answer: what the reference leaves in var[vel1X], var[duration0], var[duration1] of its Trajectory
+ * (onedpath_ip.cpp:47-52, read by printState 997-1006), plus the two progress words.  32 bytes = one HBM sector. */
+typedef struct {
+    double vel1, duration0, duration1;
+    int32_t iters;   /* Newton steps taken since the last init / set_state / set_problems (gated + ungated) */
+    uint32_t status; /* RP_ST_* */
+} rp_solution;
+
 /* ---- library ---- */
 RP_API const char *rp_version(void);
 RP_API int rp_abi_version(void);       /* RP_ABI_VERSION of the library's own build */
@@ -136,8 +146,10 @@ RP_API int rp_batch_set_problems(rp_batch *b, const double *pos0, const double *
 /* Same with device-resident inputs (no PCIe in the path).  Asynchronous: the three arrays are read, in the batch's stream order,
  * by this call's kernels only (they are copied), so they may be overwritten by later work on that stream.  The call computes the
  * batch's internal order and stops there: the start state itself is formed in registers by a fused rp_batch_solve
- * (steps_per_launch <= 0) that follows, or written out by whichever other call touches the state first -- same bits either way,
- * and nothing a caller can observe except that "positions in, solutions out" costs one launch of state traffic less. */
+ * (steps_per_launch <= 0) that follows, or written out by whichever other call touches the state first -- same bits either way.
+ * What a caller can observe of the deferral: "positions in, solutions out" costs one launch of state traffic less; the start
+ * is the one of rp_params.accel_limit AS IT WAS when the problems were set (rp_batch_set_params writes the start out before
+ * it changes the limit); raw pointers from rp_batch_field_ptr are undefined until the next state-touching call. */
 RP_API int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double *d_pos1, const double *d_pos2);
 /* Back to the feasible start of the positions the batch already holds (the `I` key for per-problem positions): nothing
  * crosses the boundary.  Asynchronous. */
@@ -177,6 +189,17 @@ RP_API int rp_batch_move_toward_feasibility(rp_batch *b);
 
 /* ---- results ---- */
 RP_API int rp_batch_get_iters(rp_batch *b, int32_t *iters, uint32_t *status); /* either may be NULL; synchronous */
+/* Solutions in PROBLEM order in DEVICE memory the caller owns (n records, 32-byte aligned): record i is problem i of the arrays
+ * handed to set_problems / set_state, whatever order the batch keeps internally -- the device-side counterpart of reading
+ * var[] of trajectory i in the reference (onedpath_ip.cpp:47-52, 997-1006); nothing crosses PCIe.  Asynchronous on the batch
+ * stream; works on any state (after steps, solves, nudges).  68 B of HBM traffic per problem. */
+RP_API int rp_batch_solution_device(rp_batch *b, rp_solution *d_out);
+/* Bind (NULL: unbind) a buffer of n records: from now on every gated solve (rp_batch_solve, rp_batch_solve_launch) writes the
+ * record of each problem it works on as that problem leaves the launch -- "positions in, solutions out in problem order" then
+ * costs no extra pass (the one 32-byte sector per problem is written under the solve's arithmetic).  After a fused solve of a
+ * batch every record is current; calls other than gated solves (rp_batch_step, nudges, set_state ...) do not update the
+ * buffer -- use rp_batch_solution_device for the state they leave.  The buffer must outlive the binding. */
+RP_API int rp_batch_bind_solution(rp_batch *b, rp_solution *d_out);
 RP_API int rp_batch_reduce(rp_batch *b, rp_reduction *out);                   /* synchronous */
 /* Writes the 4 doubles of rp_reduction to device memory the caller owns, asynchronously on
  * the batch stream: the buffer a multi-GPU caller hands to its RCCL all-reduce. */
@@ -192,6 +215,7 @@ RP_API int rp_batch_sample(rp_batch *b, double *pos66, double *acc4);
 
 /* The same into DEVICE memory the caller owns (n x 66 and n x 4 doubles), asynchronously on the batch stream: for a consumer
  * that draws from device memory, and what bench.py times (nothing crosses PCIe). */
+/* d_pos66 must be 16-byte aligned (positions are written as 16-byte vectors): RP_ERR_INVALID otherwise. */
 RP_API int rp_batch_sample_device(rp_batch *b, double *d_pos66, double *d_acc4);
 
 /* The same for problems [first, first + count) only (what onDraw needs for the watched problem). Synchronous. */
@@ -203,6 +227,9 @@ RP_API int rp_batch_sample_range(rp_batch *b, size_t first, size_t count, double
 RP_API int rp_batch_constraints_range(rp_batch *b, size_t first, size_t count, double *rows);
 
 /* ---- stream / timing plumbing ---- */
+/* Bandwidth calibration: the one-launch-per-step kernel with NO step -- its loads and stores of every problem's state and
+ * nothing else (the state is rewritten unchanged).  What bench.py prices the k = 1 launch against.  Asynchronous. */
+RP_API int rp_batch_traffic_probe(rp_batch *b);
 RP_API int rp_batch_sync(rp_batch *b);
 RP_API int rp_batch_stream(rp_batch *b, void **stream);
 /* HIP events on the batch's own stream: record slot 0..7, elapsed between two recorded slots. */
@@ -212,7 +239,8 @@ RP_API int rp_batch_event_elapsed_ms(rp_batch *b, int slot_start, int slot_stop,
  * order: the batch keeps its problems sorted for the gated solve (set_problems / set_state decide the order), problem i's
  * element is ptr[slot_of_problem[i]] with the map of rp_batch_slot_map.  Asking for an end-velocity field
  * (vel0X / vel2X) makes the batch assume they may become non-zero (general kernels) until the next init /
- * set_problems / set_state. */
+ * set_problems / set_state.  A pointer taken earlier is undefined between rp_batch_set_problems(_device) and the next call
+ * that touches the state (the feasible start is written lazily): take it again after set_problems. */
 RP_API int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr);
 /* slot_of_problem[i] = position of problem i inside the batch's field arrays (n words; the identity after
  * init_default / init_stuck).  Every other entry point takes and returns problem order; only rp_batch_field_ptr

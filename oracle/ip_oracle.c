@@ -533,7 +533,22 @@ int orc_colpiv_qr_solve_dynamic(int n, const double *A, const double *b, double 
 
 /* ------------------------------------------------------------------ */
 /* moveInteriorPoint, onedpath_ip.cpp:810-953 (F4: onedpath2_ip.cpp:698-841). */
+static void step_with(int variant, double *var, double *d, orc_step_info *info, orc_qr_solver solver, double backtrack, int max_bt);
+
 void orc_step_ex(int variant, double *var, double *d, orc_step_info *info, orc_qr_solver solver)
+{
+    step_with(variant, var, d, info, solver, 0.5, 100);      /* the reference's constants, :919, :927, :934, :944 */
+}
+
+/* The same step with the two line-search constants the reference compiles in (backtrack factor 0.5, budget of 100 halvings per
+ * loop) as parameters: what rp_params.backtrack / max_backtracks change on the device.  Not reference behaviour unless (0.5, 100). */
+void orc_step_params(int variant, double *var, orc_step_info *info, double backtrack, int max_bt)
+{
+    double d[MAXN];
+    step_with(variant, var, d, info, NULL, backtrack, max_bt);
+}
+
+static void step_with(int variant, double *var, double *d, orc_step_info *info, orc_qr_solver solver, double backtrack, int max_bt)
 {
     const int m = orc_num_constraints(variant);
     const int c = NV + m;
@@ -557,20 +572,20 @@ void orc_step_ex(int variant, double *var, double *d, orc_step_info *info, orc_q
     }
     s *= 0.99;
 
-    for (i = 0; i < 100; ++i) {                                      /* :919-928 */
+    for (i = 0; i < max_bt; ++i) {                                   /* :919-928 (100) */
         trajectory_step(variant, var, d, s, trial);
         if (orc_constraints_satisfied(variant, trial)) break;
-        s *= 0.5;
+        s *= backtrack;                                              /* 0.5 */
         ++feas_h;
     }
 
     r0 = orc_residual_norm(variant, var, perturbation);              /* :932 */
-    for (i = 0; i < 100; ++i) {                                      /* :934-945 */
+    for (i = 0; i < max_bt; ++i) {                                   /* :934-945 (100) */
         double rn;
         trajectory_step(variant, var, d, s, trial);
         rn = orc_residual_norm(variant, trial, perturbation);
         if (rn <= r0 * (1.0 - 0.01 * s)) break;
-        s *= 0.5;
+        s *= backtrack;                                              /* 0.5 */
         ++res_h;
     }
 
@@ -729,6 +744,19 @@ void orc_batch_steps(int variant, size_t n, double *aos, int k, int threads)
     for (i = 0; i < (long long)n; ++i) {
         int s;
         for (s = 0; s < k; ++s) orc_step(variant, aos + (size_t)i * M, NULL);
+    }
+}
+
+void orc_batch_steps_params(int variant, size_t n, double *aos, int k, int threads, double backtrack, int max_bt)
+{
+    const size_t M = (size_t)orc_state_len(variant);
+    const int nt = pick_threads(threads);
+    long long i;
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (i = 0; i < (long long)n; ++i) {
+        int s;
+        for (s = 0; s < k; ++s) orc_step_params(variant, aos + (size_t)i * M, NULL, backtrack, max_bt);
     }
 }
 

@@ -95,6 +95,10 @@ void   orc_step_dir(int variant, double *var, double *d /* 3+m */, orc_step_info
    solver(n, A_colmajor, b, x, force_dynamic) returns nonzero pivots; NULL = orc_colpiv_qr_solve */
 typedef int (*orc_qr_solver)(int n, const double *A, const double *b, double *x, int force_dynamic);
 void   orc_step_ex(int variant, double *var, double *d, orc_step_info *info, orc_qr_solver solver);
+/* the step with the reference's two compiled-in line-search constants (backtrack factor 0.5, 100 halvings per loop) as
+   parameters -- the oracle for rp_params.backtrack / max_backtracks; (0.5, 100) is orc_step */
+void   orc_step_params(int variant, double *var, orc_step_info *info, double backtrack, int max_bt);
+void   orc_batch_steps_params(int variant, size_t n, double *aos, int k, int threads, double backtrack, int max_bt);
 void   orc_move_toward_feasibility(int variant, double *var);
 
 void   orc_init_default(int variant, double *var);

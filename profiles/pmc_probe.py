@@ -6,7 +6,8 @@ known number of steps at 1 Mi problems:
     F4 f32          50 fused ungated steps   -> k_steps_chunks<float, float, 4, true>     (BASELINE configs[4] itself: F4's line search
     F4 f32 state    50 fused ungated steps   -> k_steps_chunks<float, double, 4, true>     only sets in from step ~6, so 12 steps undercount)
 then the gated kernel (k_solve_chunks) on 524,288 identical default problems (15 steps each: its instructions per step without idle lanes),
-the benchmark's gated solve (occupancy / busy counters of the real launch) and one k = 1 launch."""
+the benchmark's gated solve (occupancy / busy counters of the real launch), one k = 1 launch, and the feasibility move
+(k_move_toward_feasibility) on 1 Mi starts with four violated rows each -- bench.py's `neighbours.feasibility_move` workload."""
 import os
 import sys
 
@@ -43,3 +44,13 @@ with rp.Batch(N) as b:
     b.restart()      # the feasible start written out (set_problems defers it to a fused solve)
     b.step(1)
     b.sync()
+# the feasibility move on 1 Mi starts pushed out of the feasible set (both durations too short: four violated rows each)
+with rp.Batch(N) as b:
+    b.set_problems(p0, p1, p2)
+    st = b.get_state()
+    st[:, 1] *= 0.7
+    st[:, 2] *= 0.7
+    for _ in range(2):
+        b.set_state(st)
+        b.move_toward_feasibility()
+        b.sync()

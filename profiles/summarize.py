@@ -82,7 +82,7 @@ json.dump(out, open(os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag),
 def real_grid(name):
     """Work-items of the 1 Mi-problem launch of a Newton kernel of the probe: one lane per problem in the chunk kernels, two
     problems per lane (16-byte accesses) in the streaming kernel."""
-    return N if name.startswith(("k_solve_chunks", "k_steps_chunks")) else N // 2
+    return N if name.startswith(("k_solve_chunks", "k_steps_chunks", "k_move_toward")) else N // 2
 
 
 sq = {}
@@ -91,7 +91,7 @@ for d in sq_dirs:
     for grid in (N, N // 2):
         for k, cs in counters(d, grid=grid).items():
             name = short(k)
-            if name.startswith(("k_newton", "k_solve", "k_steps")) and grid == real_grid(name):
+            if name.startswith(("k_newton", "k_solve", "k_steps", "k_move_toward")) and grid == real_grid(name):
                 sq.setdefault(name, {}).update(cs)
             elif name.startswith("k_solve_chunks<double, double, 3, false, true") and grid == N // 2:
                 ident.update(cs)      # the gated kernel on 524,288 identical default problems (pmc_probe.py)
@@ -132,6 +132,14 @@ if "SQ_INSTS_VALU_FMA_F64" in ident:
 gated_real = sq.get(GATED, {})
 if "SQ_INSTS_VALU" in gated_real:
     top["_valu_wave_insts_per_gated_launch"] = gated_real["SQ_INSTS_VALU"]      # the benchmark's launch itself (idle lanes included)
+for name, c in sq.items():      # the feasibility move: one launch over 1 Mi starts with four violated rows each (pmc_probe.py)
+    if name.startswith("k_move_toward_feasibility<double, double, 3") and "SQ_INSTS_VALU_FMA_F64" in c:
+        c["flop_f64_per_problem"] = 64.0 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"]
+                                           + c["SQ_INSTS_VALU_TRANS_F64"]) / N
+        top["_flop_per_feasibility_move_4_rows"] = c["flop_f64_per_problem"]
+        if "SQ_INSTS_VALU" in c:
+            c["valu_insts_per_problem"] = 64.0 * c["SQ_INSTS_VALU"] / N
+            top["_valu_insts_per_feasibility_move_4_rows"] = c["valu_insts_per_problem"]
 sq.update(top)
 json.dump({"_method": "rocprofv3 --pmc <SQ counters, <= 8 per pass> -- python3 profiles/pmc_probe.py (1 Mi problems: 12 fused ungated steps "
                       "of F3 f64, 50 of F4 f32 / F4 f32-state, then the fused gated F3 solve and one k = 1 launch); SQ_WAVE_CYCLES / "
@@ -141,3 +149,30 @@ json.dump({"_method": "rocprofv3 --pmc <SQ counters, <= 8 per pass> -- python3 p
           open(os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("k_") or "<" not in k}, indent=1)[:3000])
 print(json.dumps(top, indent=1))
+
+# which sources these numbers belong to: bench.py withholds every counter-derived fraction once the kernel sources differ
+import hashlib  # noqa: E402
+import subprocess  # noqa: E402
+
+KERNEL_SOURCES = ("rocket_path_amd/csrc/ip_core.h", "rocket_path_amd/csrc/ip_kernels.hip", "rocket_path_amd/csrc/feas_core.h")
+box_hashes = {}      # sha256sum output the collection script wrote next to the counter directories, on the box that ran the kernels
+try:
+    for line in open(os.path.join(os.path.dirname(os.path.normpath(sq_dirs[0])), "sources.sha256")):
+        h, f = line.split()
+        if f in KERNEL_SOURCES:
+            box_hashes[f] = h[:16]
+    if len(box_hashes) != len(KERNEL_SOURCES):
+        box_hashes = {}
+except Exception:
+    box_hashes = {}
+try:
+    commit = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
+    dirty = bool(subprocess.run(["git", "status", "--porcelain", "--"] + list(KERNEL_SOURCES), cwd=ROOT, capture_output=True, text=True).stdout.strip())
+except Exception:
+    commit, dirty = None, None
+json.dump({"_what": "kernel sources the %s_* counter summaries were collected from (the .so that ran on the GPU box was built from these files); "
+                    "bench.py compares the hashes with the files it finds" % tag,
+           "commit": commit, "kernel_sources_uncommitted_at_collection": dirty,
+           "sha256_16": box_hashes or {f: hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest()[:16] for f in KERNEL_SOURCES},
+           "hashes_taken": "on the GPU box by the collection script" if box_hashes else "where the summaries were folded (no sources.sha256 in the collection)"},
+          open(os.path.join(ROOT, "profiles", "%s_sources.json" % tag), "w"), indent=1)

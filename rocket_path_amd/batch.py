@@ -132,6 +132,18 @@ class Batch:
         capi.check(self._lib.rp_batch_get_iters(self._h, _ptr(it), _ptr(st)))
         return it, st
 
+    def solution_device(self, d_out):
+        """Every problem's 32-byte rp_solution record, in problem order, into device memory (address of n records)."""
+        capi.check(self._lib.rp_batch_solution_device(self._h, ctypes.c_void_p(d_out)))
+
+    def bind_solution(self, d_out):
+        """Gated solves write each problem's rp_solution record to d_out (device address of n records; None / 0 unbinds)."""
+        capi.check(self._lib.rp_batch_bind_solution(self._h, ctypes.c_void_p(d_out) if d_out else None))
+
+    def traffic_probe(self):
+        """The k = 1 kernel's loads and stores with no step (bandwidth calibration)."""
+        capi.check(self._lib.rp_batch_traffic_probe(self._h))
+
     def reduce(self):
         r = capi.Reduction()
         capi.check(self._lib.rp_batch_reduce(self._h, ctypes.byref(r)))

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librp_batch.so")
 
 RP_OK = 0
-ABI_VERSION = 3      # RP_ABI_VERSION of include/rp_batch.h this binding was written against
+ABI_VERSION = 4      # RP_ABI_VERSION of include/rp_batch.h this binding was written against
 RP_ERR_INVALID, RP_ERR_DEVICE, RP_ERR_NOMEM, RP_ERR_UNSUPPORTED, RP_ERR_NO_DEVICE = 1, 2, 3, 4, 5
 VARIANT_F3, VARIANT_F4 = 3, 4
 DTYPE_F64, DTYPE_F32, DTYPE_F32_STATE = 0, 1, 2      # 2: fp32 state in HBM, fp64 arithmetic (include/rp_batch.h)
@@ -29,6 +29,16 @@ class Params(ctypes.Structure):
                 ("boundary_fraction", ctypes.c_double), ("backtrack", ctypes.c_double),
                 ("armijo", ctypes.c_double), ("max_backtracks", ctypes.c_int32), ("stall_window", ctypes.c_int32),
                 ("mu_mode", ctypes.c_int32), ("mu_sigma_try", ctypes.c_double * 2)]
+
+
+class Solution(ctypes.Structure):
+    """rp_solution: one problem's answer, 32 bytes (as a numpy record: SOLUTION_FIELDS)."""
+    _fields_ = [("vel1", ctypes.c_double), ("duration0", ctypes.c_double), ("duration1", ctypes.c_double),
+                ("iters", ctypes.c_int32), ("status", ctypes.c_uint32)]
+
+
+# numpy dtype description of an array of rp_solution records (np.dtype(SOLUTION_FIELDS), itemsize 32)
+SOLUTION_FIELDS = [("vel1", "<f8"), ("duration0", "<f8"), ("duration1", "<f8"), ("iters", "<i4"), ("status", "<u4")]
 
 
 class Reduction(ctypes.Structure):
@@ -69,6 +79,9 @@ SIGNATURES = {
     "rp_batch_solve_launch": (ctypes.c_int, [_vp, ctypes.c_double, ctypes.c_int, ctypes.c_int]),
     "rp_batch_move_toward_feasibility": (ctypes.c_int, [_vp]),
     "rp_batch_get_iters": (ctypes.c_int, [_vp, _vp, _vp]),
+    "rp_batch_solution_device": (ctypes.c_int, [_vp, _vp]),
+    "rp_batch_bind_solution": (ctypes.c_int, [_vp, _vp]),
+    "rp_batch_traffic_probe": (ctypes.c_int, [_vp]),
     "rp_batch_reduce": (ctypes.c_int, [_vp, ctypes.POINTER(Reduction)]),
     "rp_batch_reduce_device": (ctypes.c_int, [_vp, _vp]),
     "rp_batch_summary_device": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),

@@ -31,15 +31,15 @@
 //    point's evaluation (the reference recomputes the same numbers; MEMO), the evaluation at
 //    the accepted trial point is carried into the next step instead of being recomputed, and in
 //    the gated kernels so are the sums its residual test was made of (residual_sums).
-//  * the kernels are fp64-ALU bound (the vector ALU issues ~97 % of the cycles), so the currency
-//    is instructions: 370-440 per Newton step.  An IEEE fp64 division costs 11 of them on gfx950
-//    (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup); every division on the path is a
-//    reciprocal, v_rcp_f64 + two Newton iterations (5 instructions, <= 1-2 ulp, the issue time
-//    of ~7 multiplications), and reciprocals are batched: one for the two durations of a trial
-//    point (the reference divides by t about 20 times per constraint sweep,
-//    onedpath_ip.cpp:385-391, 404-410), one for all constraints, one for the two arrow pivots,
-//    one for the boundary fraction -- 5 per step where the first version of this file had 19.
-//    Define RP_EXACT_DIV to build with correctly rounded divisions instead (A/B builds).
+//  * the kernels are fp64-ALU bound (the vector ALU issues ~80 % of the cycles of a power-capped clock), so the
+//    currency is instructions: ~300 per gated Newton step (profiles/r4_sq_counters.json has the count of the
+//    shipped kernels).  An IEEE fp64 division costs 11 of them on gfx950 (v_div_scale x2, v_rcp, 5 fma,
+//    v_div_fmas, v_div_fixup); every division on the path is a reciprocal, v_rcp_f64 + ONE cubic refinement
+//    (rcp_ below: 4 instructions, correctly rounded but for ~1e-7 of the inputs, the issue time of ~6
+//    multiplications), and reciprocals are batched: one for the two durations of a trial point (the reference
+//    divides by t about 20 times per constraint sweep, onedpath_ip.cpp:385-391, 404-410), one for all
+//    constraints, one for the two arrow pivots, one for the boundary fraction -- 4-5 per step where the first
+//    version of this file had 19.  Define RP_EXACT_DIV to build with correctly rounded divisions instead (A/B builds).
 //  * template switches of newton_step: MEMO (fixed-step kernels: exact memoisation for the
 //    reference's post-convergence regime), AFFINE (with MEMO: that regime's residual loop on affine
 //    pieces), MU (rp_params.mu_mode), a bookkeeping hook (halving counts for rp_batch_step_counted).
@@ -86,9 +86,13 @@ template <> __device__ __forceinline__ float rcp_<float>(float x) { return 1.0f 
 #else
 template <> __device__ __forceinline__ double rcp_<double>(double x)
 {
-    // v_rcp_f64 is good to 2^-24 (4.6e-8 measured); ONE cubic refinement, r (1 + e + e^2) with e = 1 - x r, leaves e^3 ~ 1e-22:
-    // three multiply-adds, bit-equal to IEEE 1/x on 4.19 M samples (profiles/probes/rcp_probe.hip), as two Newton steps -- four
-    // multiply-adds, what this was until late in round 3 -- are.  (One Newton step, 10 ulp, fails parity: profiles/r3_tuning.md.)
+    // v_rcp_f64 is good to 2^-24 (4.6e-8 measured); ONE cubic refinement, r (1 + e + e^2) with e = 1 - x r, leaves a truncation
+    // error e^3 ~ 1e-22 relative before the final rounding: three multiply-adds.  That is CORRECTLY ROUNDED EXCEPT WITH
+    // PROBABILITY ~1e-7 per input (e^3 / half an ulp; no misrounding among 4.19 M samples, profiles/probes/rcp_probe.hip) -- not
+    // IEEE-exact: a 1 Mi-problem solve makes ~1e8 reciprocals and will contain a few 1-ulp differences from true division, from
+    // the RP_EXACT_DIV build and from the two Newton steps (four multiply-adds, misrounding ~1e-13) this was until late in
+    // round 3.  "Bit-identical" claims elsewhere are A/B comparisons between builds that share this function.
+    // (One Newton step, 10 ulp, fails parity: profiles/r3_tuning.md.)
     const double r = __builtin_amdgcn_rcp(x);
     const double e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, __builtin_fma(e, e, e), r);
@@ -897,15 +901,20 @@ __device__ __forceinline__ int skip_certain_halvings(const P &k, const KParams<T
         if constexpr (RP_FEAS_RAY && !P::lean) {
             const RayProof<T> ray = ray_proof<T, P>(k, L, v, t0, t1, dxv, dx0, dx1, s);
             if (kp.backtrack == T(0.5)) {
-                // The number of proven halvings by bisection, no loop over them.  g is a quadratic with g(0) <= 0 wherever x itself is
-                // not beyond doubt infeasible: if g(s) > 0 at the first trial, g > 0 exactly on the trials down to a root and <= 0 below
-                // it (convex: g increases beyond its one positive root; concave: g >= the smaller of two positive values in
-                // between), so "g(s 2^-k) > 0" is true up to some k and false from there on.  Seven probes find the last true k in
-                // [0, 127]; every counted halving lies between two EVALUATED positives.  (g(0) > 0: all 127 hold, the budget caps it.)
+                // The number of proven halvings by bisection, no loop over them.  The bisection needs "g(s 2^-k) > 0" to be true up to
+                // some k and false from there on.  With g(0) <= 0 (x itself not beyond doubt infeasible) and g(s) > 0 at the first trial
+                // that holds for any quadratic: convex, g increases beyond its one positive root; concave, g >= the smaller of two
+                // positive values in between.  With g(0) > 0 (x itself beyond doubt infeasible: a nudged or set state, an
+                // RP_ST_INFEASIBLE start, a point the residual loop accepted outside) it still holds for a concave or linear g, which is
+                // then positive on all of [0, s] -- all 127 probes hold and the budget caps the count, as the reference's loop runs
+                // out of halvings -- but NOT for a convex one, which may dip below zero in between (10 - 140 s + 200 s^2): there the
+                // closed form is not used and the per-trial proof below, sequential and always sound, walks the trials.
+                // Seven probes find the last true k in [0, 127]; every counted halving lies between two EVALUATED positives.
+                const bool monotone = !(ray.g0 > T(0)) || !(ray.g2 > T(0));
                 int last = 0;
 #pragma unroll
                 for (int b = 64; b >= 1; b >>= 1) last += ray.holds(ldexp_(s, -(last + b))) ? b : 0;
-                int proven = (ray.on && ray.holds(s)) ? last + 1 : 0;
+                int proven = (ray.on && monotone && ray.holds(s)) ? last + 1 : 0;
                 proven = proven < kp.max_bt ? proven : kp.max_bt;
                 s = ldexp_(s, -proven);
                 it_feas = proven;

@@ -15,6 +15,13 @@ struct StartRecord {
     long long problem;      // the problem's own index (diagnostic; nothing on the path reads it)
 };
 
+// One problem's answer, 32 bytes = one sector (the layout of rp_solution in include/rp_batch.h)
+struct Solution {
+    double vel1, duration0, duration1;
+    int32_t iters;
+    uint32_t status;
+};
+
 // Device-side view of one batch: `fields` SoA arrays of `n` elements, field f of the problem at POSITION s at
 // base + f * stride + s (stride >= n, an odd multiple of 512 elements: 2-4 KiB aligned fields that do not alias in HBM, rp_batch.cpp).
 struct BatchView {
@@ -32,6 +39,8 @@ struct BatchView {
                            // feasible start -- or the fused solve -- of a fresh batch gathers through prob_of.  Null until the
                            // first set_problems
     bool scheduled;        // false: the problems lie in problem order (identical problems of initDefault / initStuck)
+    Solution *solution;    // bound by rp_batch_bind_solution (null: none): gated solves write each problem's record there, problem order
+    int iters_add;         // ungated steps taken since the last init, added to the iteration counts that leave the batch in records
     unsigned long long *counters;   // 128 words: [0,64) shards of "problems still open after the last gated launch", [64,128) shards of gated steps executed
 };
 
@@ -60,6 +69,9 @@ hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double g
 // max ||r||^2, max gap, #converged, gated steps (+ host_steps) -> d_out4 (device); d_partials has 4 * 1024 doubles.
 hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_steps, double *d_partials,
                          double *d_out4, hipStream_t stream);
+
+// every problem's 32-byte solution record in problem order (walks positions, scatters whole sectors)
+hipError_t launch_solution(const BatchView &b, Solution *d_out, hipStream_t stream);
 
 // state movement / initialisation
 hipError_t launch_aos_to_soa(const BatchView &b, const double *d_aos, hipStream_t stream);

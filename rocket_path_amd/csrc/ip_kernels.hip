@@ -77,6 +77,17 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
     return kp;
 }
 
+// one problem's answer as its 32-byte record: two 16-byte nontemporal stores = one whole sector
+__device__ __forceinline__ void store_solution(Solution *rec, double v, double t0, double t1, int it, uint32_t st)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const unsigned long long words = ((unsigned long long)st << 32) | (unsigned long long)(uint32_t)it;      // little endian: iters, then status
+    const v2 a = {v, t0}, b = {t1, __longlong_as_double((long long)words)};
+    v2 *dst = reinterpret_cast<v2 *>(rec);
+    __builtin_nontemporal_store(a, dst);
+    __builtin_nontemporal_store(b, dst + 1);
+}
+
 // ---------------------------------------------------------------------------------------
 // run_lane: up to k Newton steps of one problem, state in registers between steps.
 //   GATED = false : exactly k steps (k presses of 'n', onedpath_ip.cpp:269-272)
@@ -283,7 +294,8 @@ template <typename S, typename T, int VARIANT, bool STALL, bool ZV, int MU = 0, 
 __global__ void __launch_bounds__(64, MU == 1 ? RP_NEWTON_WAVES : (STALL && RP_GATED_WAVES > 3) ? 3 : RP_GATED_WAVES)
 k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
                int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
-               const StartRecord *__restrict__ records, const uint32_t *__restrict__ prob_of, double start_limit)
+               const StartRecord *__restrict__ records, const uint32_t *__restrict__ prob_of, double start_limit,
+               Solution *__restrict__ solution, const uint32_t *__restrict__ sol_prob_of, int iters_add)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;   // first constant field: pos0, vel0, pos1, pos2, vel2
@@ -385,6 +397,14 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
             st_once(g + 2 * stride, (S)t1);
 #pragma unroll
             for (int c = 0; c < NC; ++c) st_once(g + (3 + c) * stride, (S)lam[c]);
+        }
+        // A bound solution buffer (rp_batch_bind_solution): the answer of the problem that lies here -- what the reference leaves in
+        // var[vel1X, duration0, duration1] of its Trajectory (onedpath_ip.cpp:47-52) -- goes straight to that problem's 32-byte
+        // record, in PROBLEM order: one whole sector per problem, scattered, under the other waves' arithmetic.  (Wave-uniform
+        // branch on a kernel argument; the problem index is loaded here, after the steps, not held through them.)
+        if (solution) {
+            const size_t prob = sol_prob_of ? (size_t)sol_prob_of[j] : j;
+            store_solution(solution + prob, (double)(S)v, (double)(S)t0, (double)(S)t1, it + iters_add, st);
         }
     }
 
@@ -768,6 +788,69 @@ k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ slot
     if (i < n) dst[i] = src[slot_of[i]];
 }
 
+// The same two transposes for a WHOLE batch in scheduled order, walking POSITIONS: a block takes 256 consecutive positions, so
+// the SoA side is coalesced as before, and the AoS side is whole rows -- problem prob_of[s]'s row of M doubles (128 B for F3:
+// four whole sectors; 96 B for F4: three), M consecutive threads per row.  The forms above, which walk problems and reach the
+// state through slot_of, touch one 32-byte sector per 8-byte field: 1,458 MB of traffic for the 268 MB a 1 Mi-problem read-back
+// is made of (5.4 x, profiles/r3_hbm_traffic.json); they stay for identity order and for the ranges a host watches.
+template <typename T, int M>
+__global__ void __launch_bounds__(kBlock)
+k_soa_to_aos_rows(const T *__restrict__ base, size_t stride, size_t n, const uint32_t *__restrict__ prob_of, double *__restrict__ aos)
+{
+    __shared__ double tile[kBlock * (M + 1)];
+    __shared__ uint32_t s_prob[kBlock];
+    const size_t row0 = (size_t)blockIdx.x * kBlock;
+    const size_t rows = (n - row0 < (size_t)kBlock) ? (n - row0) : (size_t)kBlock;
+    if (threadIdx.x < rows) {
+        const size_t at = row0 + threadIdx.x;
+        s_prob[threadIdx.x] = prob_of[at];
+#pragma unroll
+        for (int f = 0; f < M; ++f) tile[threadIdx.x * (M + 1) + f] = (double)ld_once(base + (size_t)f * stride + at);
+    }
+    __syncthreads();
+    for (size_t j = threadIdx.x; j < rows * M; j += kBlock) {
+        const size_t r = j / M, f = j % M;
+        __builtin_nontemporal_store(tile[r * (M + 1) + f], aos + (size_t)s_prob[r] * M + f);
+    }
+}
+
+template <typename T, int M>
+__global__ void __launch_bounds__(kBlock)
+k_aos_rows_to_soa(const double *__restrict__ aos, T *__restrict__ base, size_t stride, size_t n, const uint32_t *__restrict__ prob_of)
+{
+    __shared__ double tile[kBlock * (M + 1)];
+    __shared__ uint32_t s_prob[kBlock];
+    const size_t row0 = (size_t)blockIdx.x * kBlock;
+    const size_t rows = (n - row0 < (size_t)kBlock) ? (n - row0) : (size_t)kBlock;
+    if (threadIdx.x < rows) s_prob[threadIdx.x] = prob_of[row0 + threadIdx.x];
+    __syncthreads();
+    for (size_t j = threadIdx.x; j < rows * M; j += kBlock) {
+        const size_t r = j / M, f = j % M;
+        tile[r * (M + 1) + f] = __builtin_nontemporal_load(aos + (size_t)s_prob[r] * M + f);
+    }
+    __syncthreads();
+    if (threadIdx.x < rows) {
+        const size_t at = row0 + threadIdx.x;
+#pragma unroll
+        for (int f = 0; f < M; ++f) base[(size_t)f * stride + at] = (T)tile[threadIdx.x * (M + 1) + f];
+    }
+}
+
+// rp_batch_solution_device: every problem's answer -- (vel1, duration0, duration1), iteration count, status word -- as a 32-byte
+// record in PROBLEM order.  Walks positions: 28 B per problem read coalesced + the 4-byte inverse map, one whole sector written
+// where prob_of says.  (k_solve_chunks writes the same records itself when a buffer is bound.)
+template <typename S>
+__global__ void __launch_bounds__(kBlock)
+k_solution(const S *__restrict__ base, size_t stride, size_t n, const int32_t *__restrict__ iters, const uint32_t *__restrict__ status,
+           const uint32_t *__restrict__ prob_of, int iters_add, Solution *__restrict__ out)
+{
+    const size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const size_t prob = prob_of ? (size_t)prob_of[s] : s;
+    store_solution(out + prob, (double)ld_once(base + s), (double)ld_once(base + stride + s), (double)ld_once(base + 2 * stride + s),
+                   iters[s] + iters_add, status[s]);
+}
+
 // Feasible start (build-defined): vel1 = 0, t_i = (3.5/sqrt 12) sqrt(6 |dX_i| / L), multipliers 1,
 // vel0 = vel2 = 0, computed in double from the positions the batch holds in its own constant fields (put there, at each
 // problem's position in the scheduled order, by schedule.hip) and stored in the batch's storage type.  This is what
@@ -1060,16 +1143,24 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     // the arithmetic dominates and k_steps_chunks runs (one problem per lane, no second register set, 152-158 VGPRs: 3 waves per
     // SIMD) at every batch size -- measured at 1 Mi problems: k = 1 5.3 TB/s (stream16) against 5.1, k = 2 0.042 ms (chunks)
     // against 0.047 (profiles/r3_k1_ab_probe.log); round 2 had drawn the line at k = 3 against the LDS-tiled form of the day.
-    static const char *grid_env = getenv("RP_STREAM_GRID");     // tuning override: forces the streaming kernel
-    static const int chunks_from = getenv("RP_CHUNKS_FROM_K") ? atoi(getenv("RP_CHUNKS_FROM_K")) : 2;      // tuning override: smallest k that takes k_steps_chunks
+    // The shipped library reads nothing from the environment: the knobs below exist in tuning builds only (-DRP_TUNING, what
+    // the probes under profiles/probes build), where they override the launch shape for A/B runs.
+#ifdef RP_TUNING
+    static const char *grid_env = getenv("RP_STREAM_GRID");     // forces the streaming kernel
+    static const int chunks_from = getenv("RP_CHUNKS_FROM_K") ? atoi(getenv("RP_CHUNKS_FROM_K")) : 2;      // smallest k that takes k_steps_chunks
+    static const bool scalar_only = getenv("RP_STREAM_SCALAR") != nullptr;      // everything through the 8-byte prefetching kernel
+#else
+    constexpr const char *grid_env = nullptr;
+    constexpr int chunks_from = 2;
+    constexpr bool scalar_only = false;
+#endif
     if (k >= chunks_from && k >= 1 && !grid_env) {
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V, Z>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
                                              (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
         return hipGetLastError();
     }
-    // k = 1: memory-bound.  Full blocks of 256 lanes x 16 B go through k_newton_stream16; the ragged remainder (and,
-    // under RP_STREAM_SCALAR=1, everything: the A/B switch of the tuning log) through the 8-byte prefetching kernel.
-    static const bool scalar_only = getenv("RP_STREAM_SCALAR") != nullptr;
+    // k = 1: memory-bound.  Full blocks of 256 lanes x 16 B go through k_newton_stream16; the ragged remainder (and, in a
+    // tuning build under RP_STREAM_SCALAR=1, everything: the A/B switch of the tuning log) through the 8-byte prefetching kernel.
     const size_t per_block = (size_t)kBlock * (b.dtype == 1 ? 4 : 2);      // problems per lane: Vec16<S, T>::PER
     const size_t nfull = (scalar_only || grid_env || k > 2) ? 0 : b.n / per_block * per_block;      // (k > 2 only under RP_STREAM_GRID)
     if (nfull > 0)
@@ -1099,25 +1190,25 @@ hipError_t launch_steps_counted(const BatchView &b, const HostParams &hp, int k,
 static hipError_t launch_chunks(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, bool from_start, hipStream_t stream)
 {
     const dim3 grid((unsigned)((b.n + 63) / 64)), block(64);
-    static const unsigned lds_pad = getenv("RP_GATED_LDS_PAD") ? (unsigned)atoi(getenv("RP_GATED_LDS_PAD")) : 0u;      // tuning: dynamic LDS per block, to cap the waves per SIMD
-    if (lds_pad) {
-        hipLaunchKernelGGL((k_solve_chunks<double, double, 3, false, true>), grid, block, lds_pad, stream, (double *)b.base, b.stride, b.n, k,
-                           make_kparams<double>(hp, 3), gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit);
-        return hipGetLastError();
-    }
+#ifdef RP_TUNING
+    // tuning builds only: dynamic LDS per block, to cap the waves per SIMD -- passed to whichever instantiation the batch selects
+    static const unsigned lds_pad = getenv("RP_GATED_LDS_PAD") ? (unsigned)atoi(getenv("RP_GATED_LDS_PAD")) : 0u;
+#else
+    constexpr unsigned lds_pad = 0u;
+#endif
     if (from_start) {      // reference mode, no stall detector, zero end velocities: rp_batch.cpp only asks for this form then
         if (hp.mu_mode != 0 || hp.stall_window > 0 || !b.zero_end_vel || !b.records) return hipErrorInvalidValue;
-        RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, false, true, 0, true>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
-                                           make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit));
+        RP_DISPATCH(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, false, true, 0, true>), grid, block, lds_pad, stream, (S *)b.base, b.stride, b.n, k,
+                                           make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit, b.solution, b.scheduled ? (const uint32_t *)b.prob_of : nullptr, b.iters_add));
     } else if (hp.mu_mode == 1)
-        RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, true, Z, 1>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
-                                                 make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit));
+        RP_DISPATCH_MU1_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, true, Z, 1>), grid, block, lds_pad, stream, (S *)b.base, b.stride, b.n, k,
+                                                 make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit, b.solution, b.scheduled ? (const uint32_t *)b.prob_of : nullptr, b.iters_add));
     else if (hp.stall_window > 0)
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, true, Z>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
-                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit));
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, true, Z>), grid, block, lds_pad, stream, (S *)b.base, b.stride, b.n, k,
+                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit, b.solution, b.scheduled ? (const uint32_t *)b.prob_of : nullptr, b.iters_add));
     else
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, false, Z>), grid, block, 0, stream, (S *)b.base, b.stride, b.n, k,
-                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit));
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_solve_chunks<S, T, V, false, Z>), grid, block, lds_pad, stream, (S *)b.base, b.stride, b.n, k,
+                                             make_kparams<T>(hp, V), (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit, b.solution, b.scheduled ? (const uint32_t *)b.prob_of : nullptr, b.iters_add));
     return hipGetLastError();
 }
 
@@ -1155,9 +1246,29 @@ hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_s
 
 static const uint32_t *slots(const BatchView &b) { return b.scheduled ? b.slot_of : nullptr; }
 
+hipError_t launch_solution(const BatchView &b, Solution *d_out, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    const uint32_t *inv = b.scheduled ? (const uint32_t *)b.prob_of : nullptr;
+    if (b.dtype == 0) hipLaunchKernelGGL((k_solution<double>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream, (const double *)b.base, b.stride, b.n, b.iters, b.status, inv, b.iters_add, d_out);
+    else              hipLaunchKernelGGL((k_solution<float>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream, (const float *)b.base, b.stride, b.n, b.iters, b.status, inv, b.iters_add, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_aos_to_soa(const BatchView &b, const double *d_aos, hipStream_t stream)
 {
     const dim3 g(grid_for(b.n)), t(kBlock);
+    if (b.scheduled) {      // whole rows in, walking positions
+        const uint32_t *inv = (const uint32_t *)b.prob_of;
+        if (b.dtype == 0) {
+            if (b.variant == 3) hipLaunchKernelGGL((k_aos_rows_to_soa<double, 16>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n, inv);
+            else                hipLaunchKernelGGL((k_aos_rows_to_soa<double, 12>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n, inv);
+        } else {
+            if (b.variant == 3) hipLaunchKernelGGL((k_aos_rows_to_soa<float, 16>), g, t, 0, stream, d_aos, (float *)b.base, b.stride, b.n, inv);
+            else                hipLaunchKernelGGL((k_aos_rows_to_soa<float, 12>), g, t, 0, stream, d_aos, (float *)b.base, b.stride, b.n, inv);
+        }
+        return hipGetLastError();
+    }
     if (b.dtype == 0) {      // storage type only: dtype 1 and 2 both keep floats
         if (b.variant == 3) hipLaunchKernelGGL((k_aos_to_soa<double, 16>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n, slots(b));
         else                hipLaunchKernelGGL((k_aos_to_soa<double, 12>), g, t, 0, stream, d_aos, (double *)b.base, b.stride, b.n, slots(b));
@@ -1182,7 +1293,20 @@ hipError_t launch_soa_to_aos_range(const BatchView &b, size_t first, size_t coun
     return hipGetLastError();
 }
 
-hipError_t launch_soa_to_aos(const BatchView &b, double *d_aos, hipStream_t stream) { return launch_soa_to_aos_range(b, 0, b.n, d_aos, stream); }
+hipError_t launch_soa_to_aos(const BatchView &b, double *d_aos, hipStream_t stream)
+{
+    if (!b.scheduled || b.n == 0) return launch_soa_to_aos_range(b, 0, b.n, d_aos, stream);
+    const dim3 g(grid_for(b.n)), t(kBlock);      // whole rows out, walking positions
+    const uint32_t *inv = (const uint32_t *)b.prob_of;
+    if (b.dtype == 0) {
+        if (b.variant == 3) hipLaunchKernelGGL((k_soa_to_aos_rows<double, 16>), g, t, 0, stream, (const double *)b.base, b.stride, b.n, inv, d_aos);
+        else                hipLaunchKernelGGL((k_soa_to_aos_rows<double, 12>), g, t, 0, stream, (const double *)b.base, b.stride, b.n, inv, d_aos);
+    } else {
+        if (b.variant == 3) hipLaunchKernelGGL((k_soa_to_aos_rows<float, 16>), g, t, 0, stream, (const float *)b.base, b.stride, b.n, inv, d_aos);
+        else                hipLaunchKernelGGL((k_soa_to_aos_rows<float, 12>), g, t, 0, stream, (const float *)b.base, b.stride, b.n, inv, d_aos);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_restart_feasible(const BatchView &b, const HostParams &hp, hipStream_t stream)
 {

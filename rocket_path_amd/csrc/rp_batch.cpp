@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <new>
 
@@ -160,7 +161,7 @@ int need_aos(rp_batch *b)
 
 extern "C" {
 
-const char *rp_version(void) { return "rocket_path_amd 0.4 (gfx950)"; }
+const char *rp_version(void) { return "rocket_path_amd 0.5 (gfx950)"; }
 int rp_abi_version(void) { return RP_ABI_VERSION; }
 size_t rp_params_size(void) { return sizeof(rp_params); }
 const char *rp_last_error(void) { return g_err; }
@@ -234,7 +235,9 @@ int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device
     // fields 1.25 KiB or more out of phase; plateau from there on).  So the stride is an ODD multiple of 512 elements.
     b->view.stride = (n + 511) / 512 * 512;
     if ((b->view.stride / 512) % 2 == 0) b->view.stride += 512;
-    if (const char *pad = getenv("RP_STRIDE_PAD")) b->view.stride += (size_t)atoi(pad) / 16 * 16;      // tuning probe only
+#ifdef RP_TUNING      // tuning builds only (profiles/probes/stride_probe.py): the shipped library reads nothing from the environment
+    if (const char *pad = getenv("RP_STRIDE_PAD")) b->view.stride += (size_t)atoi(pad) / 16 * 16;
+#endif
     b->view.zero_end_vel = true;       // the state starts all-zero
     b->view.scheduled = false;         // ... and identical problems lie in problem order
     const size_t fields = (size_t)rp::state_len(variant);
@@ -298,6 +301,14 @@ int rp_batch_set_params(rp_batch *b, const rp_params *p)
         if (b->view.dtype == RP_DTYPE_F32) return fail(RP_ERR_UNSUPPORTED, "mu_mode 1 needs double arithmetic (RP_DTYPE_F64 or RP_DTYPE_F32_STATE)");
         if (!(p->mu_sigma_try[0] > 0 && p->mu_sigma_try[0] <= p->mu_sigma_try[1] && p->mu_sigma_try[1] < 1))
             return fail(RP_ERR_INVALID, "mu_sigma_try must satisfy 0 < [0] <= [1] < 1");
+    }
+    if (b->at_start && p->accel_limit != b->params.accel_limit) {
+        // the feasible start of a batch that has just been given its problems is formed lazily, from the limit of the moment the
+        // problems were set: write it out before the limit changes (set_problems, set_params, solve = the start of the OLD limit,
+        // as if set_problems had written it)
+        RP_HIP(hipSetDevice(b->device));
+        const int ms = materialize(b);
+        if (ms != RP_OK) return ms;
     }
     b->params.accel_limit = p->accel_limit;
     b->params.mu_divisor = p->mu_divisor;
@@ -494,11 +505,16 @@ int rp_batch_step(rp_batch *b, int k)
 {
     RP_NEED_STATE(b);
     if (k < 0 || k > 1000000) return fail(RP_ERR_INVALID, "step count %d out of range (0..1000000)", k);
-    // k == 0 is a no-op, except under RP_STREAM_PROBE=1 where it launches the step kernel with no
-    // steps: the same 16 loads and 11 stores per problem and nothing else (bandwidth calibration).
-    if (k == 0 && !getenv("RP_STREAM_PROBE")) return RP_OK;
+    if (k == 0) return RP_OK;
     RP_HIP(rp::launch_steps(b->view, b->params, k, b->stream));
     b->ungated_steps += (double)k;
+    return RP_OK;
+}
+
+int rp_batch_traffic_probe(rp_batch *b)
+{
+    RP_NEED_STATE(b);
+    RP_HIP(rp::launch_steps(b->view, b->params, 0, b->stream));      // the k = 1 kernel with no steps: its loads and stores, nothing else
     return RP_OK;
 }
 
@@ -538,10 +554,12 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
         const bool from_start = b->at_start && b->params.mu_mode == 0 && b->params.stall_window == 0 && b->view.zero_end_vel && max_iter > 0;
         if (from_start) b->at_start = false;
         else { const int ms = materialize(b); if (ms != RP_OK) return ms; }
+        b->view.iters_add = (int)b->ungated_steps;
         RP_HIP(rp::launch_solve_fused(b->view, b->params, gap_tol, max_iter, from_start, b->stream));
         return RP_OK;
     }
     { const int ms = materialize(b); if (ms != RP_OK) return ms; }
+    b->view.iters_add = (int)b->ungated_steps;
     // bounded host loop: every launch either finishes a problem or advances it by >= 1 step
     const int max_launches = max_iter / steps_per_launch + 2;
     for (int l = 0; l < max_launches; ++l) {
@@ -561,6 +579,7 @@ int rp_batch_solve_launch(rp_batch *b, double gap_tol, int max_iter, int k)
     if (max_iter < 0 || max_iter > 1000000) return fail(RP_ERR_INVALID, "max_iter %d out of range (0..1000000)", max_iter);
     if (k < 1 || k > 1000000) return fail(RP_ERR_INVALID, "steps per launch %d out of range (1..1000000)", k);
     if (!(gap_tol == gap_tol)) return fail(RP_ERR_INVALID, "gap_tol is NaN");
+    b->view.iters_add = (int)b->ungated_steps;
     RP_HIP(rp::launch_solve(b->view, b->params, k, gap_tol, max_iter, b->stream));
     return RP_OK;
 }
@@ -592,6 +611,24 @@ int rp_batch_get_iters(rp_batch *b, int32_t *iters, uint32_t *status)
         const int32_t add = (int32_t)b->ungated_steps;
         for (size_t i = 0; i < n; ++i) iters[i] += add;
     }
+    return RP_OK;
+}
+
+int rp_batch_solution_device(rp_batch *b, rp_solution *d_out)
+{
+    RP_NEED_STATE(b);
+    if (!d_out) return fail(RP_ERR_INVALID, "null output");
+    if (((uintptr_t)d_out & 31u) != 0) return fail(RP_ERR_INVALID, "solution records must be 32-byte aligned");
+    b->view.iters_add = (int)b->ungated_steps;
+    RP_HIP(rp::launch_solution(b->view, reinterpret_cast<rp::Solution *>(d_out), b->stream));
+    return RP_OK;
+}
+
+int rp_batch_bind_solution(rp_batch *b, rp_solution *d_out)
+{
+    if (!b) return fail(RP_ERR_INVALID, "null batch handle");
+    if (((uintptr_t)d_out & 31u) != 0) return fail(RP_ERR_INVALID, "solution records must be 32-byte aligned");
+    b->view.solution = reinterpret_cast<rp::Solution *>(d_out);
     return RP_OK;
 }
 
@@ -663,6 +700,7 @@ int rp_batch_sample_device(rp_batch *b, double *d_pos66, double *d_acc4)
 {
     RP_NEED_STATE(b);
     if (!d_pos66 || !d_acc4) return fail(RP_ERR_INVALID, "null output");
+    if (((uintptr_t)d_pos66 & 15u) != 0) return fail(RP_ERR_INVALID, "d_pos66 must be 16-byte aligned (the positions are written as 16-byte vectors)");
     RP_HIP(rp::launch_sample(b->view, d_pos66, d_acc4, b->stream));
     return RP_OK;
 }

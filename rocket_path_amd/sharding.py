@@ -14,11 +14,13 @@ from .problems import shard_range  # noqa: F401  (re-exported)
 SUMMARY_FIELDS = ("max_residual_sq", "max_gap", "n_converged", "total_steps")
 
 
-def allreduce_summary(local4, group=None):
-    """In-place reduce of the 4-double summary tensor [max_r2, max_gap, n_conv, steps]."""
+def allreduce_summary(local4, group=None, force=False):
+    """In-place reduce of the 4-double summary tensor [max_r2, max_gap, n_conv, steps].
+    force: run the two collectives even in a group of one rank (the backend's code path end to end: bench.py
+    --force-process-group, RCCL on the one GPU there is); the result is then the input."""
     if local4.numel() != 4 or local4.dtype != torch.float64:
         raise ValueError("summary must be 4 float64 values")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(local4[:2], op=dist.ReduceOp.MAX, group=group)
         dist.all_reduce(local4[2:], op=dist.ReduceOp.SUM, group=group)
     return local4

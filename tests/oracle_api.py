@@ -169,6 +169,8 @@ class Oracle:
         L.orc_colpiv_qr_solve_dynamic.argtypes = [ctypes.c_int, _dp, _dp, _dp]
         L.orc_batch_init_feasible.argtypes = [ctypes.c_int, ctypes.c_size_t, _dp, _dp, _dp, _dp]
         L.orc_batch_steps.argtypes = [ctypes.c_int, ctypes.c_size_t, _dp, ctypes.c_int, ctypes.c_int]
+        L.orc_batch_steps_params.argtypes = [ctypes.c_int, ctypes.c_size_t, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+        L.orc_step_params.argtypes = [ctypes.c_int, _dp, ctypes.POINTER(StepInfo), ctypes.c_double, ctypes.c_int]
         L.orc_batch_solve_gated.restype = ctypes.c_int64
         L.orc_batch_solve_gated.argtypes = [ctypes.c_int, ctypes.c_size_t, _dp, ctypes.c_double, ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_int32), ctypes.c_int]
@@ -302,6 +304,15 @@ class Oracle:
                 for _ in range(k):
                     self.step(variant, row)
         return aos
+
+    def batch_steps_params(self, variant, aos, k, backtrack, max_bt, threads=0):
+        """k steps with the line search's backtrack factor and halving budget as parameters ((0.5, 100) = the reference)."""
+        assert aos.flags.c_contiguous and aos.dtype == np.float64
+        self.lib.orc_batch_steps_params(variant, aos.shape[0], _p(aos), k, threads, backtrack, max_bt)
+        return aos
+
+    def step_params(self, variant, var, backtrack, max_bt, info=None):
+        self.lib.orc_step_params(variant, _p(var), ctypes.byref(info) if info is not None else None, backtrack, max_bt)
 
     def batch_solve_gated(self, variant, aos, tol=1e-8, max_iter=200, threads=0):
         assert aos.flags.c_contiguous and aos.dtype == np.float64

@@ -95,23 +95,37 @@ def test_headless_shell_without_gpu_fails_cleanly():
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/problem.h"), reason="reference tree not present (GPU box)")
-def test_plugin_compiles_against_the_reference_problem_header(tmp_path):
-    """The drop-in claim of INTEGRATION.md: BatchedOneDPathIP derives from the reference's own
-    `struct Problem` (problem.h:3-14) when built inside the reference tree, and can stand in
-    rocket_path.cpp's table of `Problem *` (rocket_path.cpp:38-44)."""
-    src = tmp_path / "dropin.cpp"
-    src.write_text(
-        '#include "batched_problem.h"\n'
-        'static BatchedOneDPathIP g_problem3(4, RP_VARIANT_F3, RP_DTYPE_F64);\n'
-        'static BatchedOneDPathIP g_problem4(4, RP_VARIANT_F4, RP_DTYPE_F32);\n'
-        'static Problem * g_problems[] = { &g_problem3, &g_problem4 };\n'
-        'int main() { for (Problem * p : g_problems) p->init(); g_problems[0]->onKey(\'n\'); return 0; }\n')
+def test_plugin_links_against_the_reference_problem_header_in_static_storage(tmp_path):
+    """The drop-in claim of INTEGRATION.md, built for real: csrc/host/static_shell.cpp holds two BatchedOneDPathIP as file-scope
+    statics in a `Problem *` table (rocket_path.cpp:33-46); here it is compiled with the REFERENCE's own problem.h
+    (RP_USE_REFERENCE_PROBLEM_H: the class derives from the reference's `struct Problem`, problem.h:3-14, and calls the shell's
+    repaint()), together with the plug-in's source, linked against librp_batch.so and run.  Without a GPU the statics'
+    constructors report the missing device before main starts and main returns 1; with one, tests/test_gpu_boundary.py runs
+    the same program through its keys."""
     host = os.path.join(ROOT, "rocket_path_amd", "csrc", "host")
-    r = subprocess.run(["g++", "-std=c++14", "-Wall", "-Werror", "-fsyntax-only", "-DRP_USE_REFERENCE_PROBLEM_H",
-                        "-I", "/root/reference", "-I", host,
-                        "-I", os.path.join(ROOT, "include"), str(src), os.path.join(host, "batched_problem.cpp")],
+    lib = os.path.join(ROOT, "rocket_path_amd", "lib")
+    exe = tmp_path / "dropin"
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-DRP_USE_REFERENCE_PROBLEM_H", "-DRP_STATIC_N=4",
+                        "-I", "/root/reference", "-I", host, "-I", os.path.join(ROOT, "include"),
+                        os.path.join(host, "static_shell.cpp"), os.path.join(host, "batched_problem.cpp"),
+                        "-L", lib, "-lrp_batch", "-Wl,-rpath," + lib, "-o", str(exe)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe), "--keys", "n s"], capture_output=True, text=True, timeout=120)
+    if rp.device_count() == 0:
+        assert run.returncode == 1 and run.stderr.count("rp_batch_create failed") == 2 and run.stdout == ""
+    else:
+        assert run.returncode == 0 and run.stderr == "" and "Duration 0:" in run.stdout
+
+
+def test_static_shell_without_gpu_fails_cleanly():
+    exe = os.path.join(ROOT, "rocket_path_amd", "lib", "rp_static")
+    if not os.path.exists(exe):
+        pytest.skip("host layer not built")
+    if rp.device_count() > 0:
+        pytest.skip("GPU present")
+    r = subprocess.run([exe, "--keys", "n s"], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.count("rp_batch_create failed") == 2 and "no HIP device" in r.stderr      # one line per static problem, printed before main
 
 
 @pytest.mark.skipif(rp.device_count() > 0, reason="a GPU is present")

@@ -451,3 +451,163 @@ def test_scheduling_stays_ordered_under_back_to_back_reuse(oracle):
         for b in batches[1:] + holders:
             b.close()
         lead.close()
+
+
+# ---- solutions in problem order, in device memory (rp_solution records) ----
+
+def _records(buf, n):
+    return buf.read(np.dtype(rp.capi.SOLUTION_FIELDS))[:n]
+
+
+@pytest.mark.parametrize("variant,dtype", [(rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F32_STATE), (rp.VARIANT_F4, rp.DTYPE_F32)])
+def test_solution_records_are_the_state_in_problem_order(variant, dtype):
+    # In the reference the answer of problem i is var[] of trajectory i (onedpath_ip.cpp:47-52, printState 997-1006).  The batch
+    # keeps its problems in scheduled order; rp_batch_solution_device hands the answers out in PROBLEM order, in device memory:
+    # bit for bit get_state()[:, :3], get_iters() -- through the separate pass and through a bound buffer the solve writes itself.
+    from hip_util import DeviceBuffer
+    n = 5 * 4096 + 129                              # ragged last chunk and last block
+    p0, p1, p2 = rp.problems.generate(808, 0, n, rp.problems.DIST_NON_MONOTONE)
+    assert np.dtype(rp.capi.SOLUTION_FIELDS).itemsize == 32 == ctypes.sizeof(rp.capi.Solution)
+    with rp.Batch(n, variant, dtype) as b, DeviceBuffer(32 * n, fill=0xff) as bound, DeviceBuffer(32 * n, fill=0xff) as sep:
+        b.bind_solution(bound.ptr)
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 40, 0)                        # F4 stalls: the cap ends it (status MAXITER), F3 converges
+        b.solution_device(sep.ptr)
+        st, (it, status) = b.get_state(), b.get_iters()
+        for rec in (_records(bound, n), _records(sep, n)):
+            assert np.array_equal(rec["vel1"], st[:, 0]) and np.array_equal(rec["duration0"], st[:, 1]) and np.array_equal(rec["duration1"], st[:, 2])
+            assert np.array_equal(rec["iters"], it) and np.array_equal(rec["status"], status)
+        assert len(np.unique(b.slot_map())) == n and not np.array_equal(b.slot_map(), np.arange(n))      # the order inside really is another one
+        # host-polled rounds: every problem's record is written by the launch the problem finishes in; the bound buffer ends complete
+        bound2 = DeviceBuffer(32 * n, fill=0xff)
+        b.bind_solution(bound2.ptr)
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 40, 3)
+        rec = _records(bound2, n)
+        assert np.array_equal(rec["vel1"], st[:, 0]) and np.array_equal(rec["iters"], it) and np.array_equal(rec["status"], status)
+        b.bind_solution(None)
+        bound2.close()
+        # ungated steps count: the records carry gated + ungated steps, as get_iters does; a bound buffer is not touched by step()
+        b.set_problems(p0, p1, p2)
+        b.step(3)
+        b.solution_device(sep.ptr)
+        rec, st3 = _records(sep, n), b.get_state()
+        assert np.array_equal(rec["duration0"], st3[:, 1]) and np.all(rec["iters"] == 3) and np.array_equal(rec["iters"], b.get_iters()[0])
+        with pytest.raises(rp.RpError):
+            b.solution_device(sep.ptr + 8)          # records are whole sectors: 32-byte alignment is demanded
+        with pytest.raises(rp.RpError):
+            b.solution_device(0)
+
+
+def test_solution_records_of_identical_problems_in_identity_order():
+    # init_default: no scheduled order (identical problems), the records are the positions themselves
+    from hip_util import DeviceBuffer
+    n = 1000
+    with rp.Batch(n) as b, DeviceBuffer(32 * n, fill=0xff) as out:
+        b.init_default()
+        b.bind_solution(out.ptr)
+        b.solve(1e-8, 200, 0)
+        rec = _records(out, n)
+        st = b.get_state()
+    assert np.all(rec["iters"] == 15) and np.all(rec["status"] == rp.ST_CONVERGED)      # first gap < 1e-8 after 15 steps
+    assert np.array_equal(rec["vel1"], st[:, 0]) and serr(rec["vel1"][0], 199.99999985997235) < 1e-12
+
+
+@pytest.mark.parametrize("variant,dtype", [(rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F32)])
+def test_whole_batch_state_transposes_walk_positions_and_round_trip(variant, dtype):
+    # get_state / set_state of a scheduled batch move whole AoS rows (k_soa_to_aos_rows / k_aos_rows_to_soa); the range
+    # read-backs keep the per-problem gather: both must tell the same story, before and after a round trip
+    n = 3 * 4096 + 1000
+    p0, p1, p2 = rp.problems.generate(99, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n, variant, dtype) as b:
+        b.set_problems(p0, p1, p2)
+        b.step(2)
+        whole = b.get_state()
+        assert np.array_equal(whole[:, -5], p0.astype(np.float32 if dtype != rp.DTYPE_F64 else np.float64))
+        for first, count in ((0, 700), (4000, 1300), (n - 5, 5)):
+            assert np.array_equal(b.get_state_range(first, count), whole[first:first + count])
+        perm = np.random.RandomState(3).permutation(n)
+        b.set_state(whole[perm])                    # the same problems handed over in another order
+        again = b.get_state()
+        assert np.array_equal(again, whole[perm])
+        b.step(1)
+        after = b.get_state()
+    with rp.Batch(n, variant, dtype) as c:
+        c.set_state(whole)
+        c.step(1)
+        assert np.array_equal(c.get_state()[perm], after)
+
+
+def test_a_limit_changed_after_set_problems_does_not_move_the_start():
+    # set_problems defers the feasible start; it is the start of the limit in force when the problems were set
+    n = 4096
+    p0, p1, p2 = rp.problems.generate(5, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as a, rp.Batch(n) as b:
+        a.set_problems(p0, p1, p2)
+        start = a.get_state()
+        b.set_problems(p0, p1, p2)
+        b.set_params(accel_limit=50.0)              # before anything has touched the state
+        assert np.array_equal(b.get_state(), start)
+        b.solve(1e-8, 200, 0)
+        _, acc = b.sample()
+        assert 49.99 < np.max(np.abs(acc)) <= 50.0 * (1 + 1e-9)      # ... while the solve obeys the new limit
+        b.restart()                                 # a restart asked for NOW uses the limit of now
+        assert not np.array_equal(b.get_state()[:, 1:3], start[:, 1:3])
+
+
+def test_sample_device_demands_16_byte_alignment():
+    from hip_util import DeviceBuffer
+    n = 256
+    with rp.Batch(n) as b, DeviceBuffer(n * 70 * 8 + 64) as out:
+        b.init_default()
+        with pytest.raises(rp.RpError):
+            b.sample_device(out.ptr + 8, out.ptr + n * 66 * 8 + 16)
+        b.sample_device(out.ptr, out.ptr + n * 66 * 8)
+        b.sync()
+
+
+# ---- the drop-in exactly as rocket_path.cpp holds it ----
+
+def test_static_storage_drop_in_runs_and_tears_down_after_main(golden_dir):
+    # csrc/host/static_shell.cpp: two 1 Mi-problem BatchedOneDPathIP as FILE-SCOPE STATICS (rocket_path.cpp:33-36), table of
+    # Problem * (38-44), init() on all from main (65-68), onActivate() (70), keys, F4 switch (148-157), return from main --
+    # HIP initialisation and 270 MB of hipMalloc before main, rp_batch_destroy from static destructors after it.
+    import json
+    exe = os.path.join(ROOT, "rocket_path_amd", "lib", "rp_static")
+    kat = json.load(open(os.path.join(golden_dir, "survey_kat.json")))
+    out = subprocess.run([exe, "--keys", "i n s n s n13 s HOME n SPACE F4 n s F3 s"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+    assert out.stderr == "", out.stderr[-2000:]                         # nothing from the keys, nothing from the destructors
+    states = [list(map(float, l.split()[1:])) for l in out.stdout.splitlines() if l.startswith("State17:")]
+    assert len(states) == 5
+    assert serr(states[0], kat["f3_default"]["after_step_1"]) < 1e-11
+    assert serr(states[1], kat["f3_default"]["after_step_2"]) < 1e-11
+    assert serr(states[2][:3], kat["f3_default"]["after_step_15_v_t0_t1"]) < 1e-12
+    assert serr(states[3][:3], kat["f4_default"]["after_step_1_v_t0_t1"]) < 1e-6      # F4 slot: fp32 state, fp64 arithmetic
+    assert "batch of 1048576 problems" in out.stdout and out.stdout.count("1D path: Interior point") == 3
+    assert "Batch: 1048576 problems" in out.stdout
+
+
+# ---- torch.distributed on the nccl (= RCCL) backend through bench.py's own code path, on the one GPU there is ----
+
+def test_bench_with_a_forced_rccl_process_group_of_one_rank():
+    # VERDICT r3 missing #1: dist.init_process_group("nccl", device_id=...), the two sliced all_reduces of sharding.py on a
+    # device tensor, HSA_ENABLE_IPC_MODE_LEGACY=0 -- the N > 1 code path -- had never met RCCL.  With --force-process-group the
+    # N = 1 run goes through all of it; its line must equal the plain run's in everything that is not a timing.
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    lines = []
+    for extra in ([], ["--force-process-group"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--problems-per-gpu", "131072",
+                              "--no-extras", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+    plain, forced = lines
+    assert plain["process_group_backend"] is None and plain["ranks_in_process_group"] == 1
+    assert forced["process_group_backend"] == "nccl" and forced["ranks_in_process_group"] == 1 and forced["n_gpus"] == 1
+    assert forced["config"]["final_summary"] == plain["config"]["final_summary"]
+    assert forced["config"]["newton_steps_per_pass_per_gpu"] == plain["config"]["newton_steps_per_pass_per_gpu"]
+    assert forced["config"]["converged_fraction"] == 1.0 and forced["value"] > 0.3 * plain["value"]
+    e2e = forced["end_to_end"]["with_solutions_in_problem_order"]
+    assert e2e["both_forms_bitwise_equal"] is True and e2e["steps_summed_from_the_records"] == forced["end_to_end"]["newton_steps_per_batch"]

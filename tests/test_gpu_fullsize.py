@@ -41,13 +41,28 @@ def test_config3_one_million_gated(oracle):
         st2 = c.get_state()
     same = it2 == it[:m]                      # a shifted problem rounds differently: a gate tie (parity_util) may move one step
     assert (~same).sum() <= 2 and np.all(np.abs(it2 - it[:m]) <= 1) and serr(st2[same, :3], st[:m, :3][same]) < 1e-10
-    # the oracle on two slices (head and tail of the batch)
-    for sl in (slice(0, 32768), slice(n - 32768, n)):
-        init = oracle.batch_init_feasible(3, p0[sl], p1[sl], p2[sl])
-        aos = init.copy()
-        it_o, _ = oracle.batch_solve_gated(3, aos, 1e-8, 200)
-        ok = keep_mask(len(it_o), certify_iteration_counts(oracle, 3, init, it[sl], it_o, 1e-8))
-        assert serr(st[sl, :3][ok], aos[ok, :3]) < 1e-10
+    # the oracle on ALL 1,048,576 problems (every host thread: 1.5 s on the GPU box's 16): iteration counts -- identical but for
+    # certified gate ties, whose number is printed -- and (v, t0, t1) at 1e-10, multipliers at 1e-9
+    _whole_batch_against_the_oracle(oracle, p0, p1, p2, it, st, "configs[2], 1,048,576 monotone problems", lam_tol=1e-9)
+
+
+def _whole_batch_against_the_oracle(oracle, p0, p1, p2, it, st, what, lam_tol=None, max_ties=8):
+    n = len(p0)
+    init = oracle.batch_init_feasible(3, p0, p1, p2)
+    aos = init.copy()
+    it_o, total = oracle.batch_solve_gated(3, aos, 1e-8, 200, threads=0)
+    ties = certify_iteration_counts(oracle, 3, init, it, it_o, 1e-8, max_ties=max_ties)
+    ok = keep_mask(n, ties)
+    err = serr(st[ok, :3], aos[ok, :3])
+    msg = "%s against the oracle in full: %d problems, %d oracle steps, %d certified gate tie(s), 0 other iteration mismatches, worst (v, t0, t1) error %.2e" % (
+        what, n, total, len(ties), err)
+    if lam_tol is not None:
+        lerr = float(np.max(np.abs(st[ok, 3:11] - aos[ok, 3:11]) / np.max(np.abs(aos[ok, 3:11]), axis=1, keepdims=True)))
+        msg += ", worst multiplier error %.2e" % lerr
+        assert lerr < lam_tol, lerr
+    print(msg)
+    assert err < 1e-10, err
+    return len(ties)
 
 
 def test_config2_65536_fixed_50_steps(oracle):
@@ -142,12 +157,7 @@ def test_non_monotone_stress_one_million(oracle):
         it, status = b.get_iters()
         st = b.get_state()
     assert np.all(np.isfinite(st)) and np.all(status == rp.ST_CONVERGED) and it.max() < 200
-    sl = slice(500000, 500000 + 16384)
-    init = oracle.batch_init_feasible(3, p0[sl], p1[sl], p2[sl])
-    aos = init.copy()
-    it_o, _ = oracle.batch_solve_gated(3, aos, 1e-8, 200)
-    ok = keep_mask(len(it_o), certify_iteration_counts(oracle, 3, init, it[sl], it_o, 1e-8))
-    assert serr(st[sl, :3][ok], aos[ok, :3]) < 1e-10
+    _whole_batch_against_the_oracle(oracle, p0, p1, p2, it, st, "the non-monotone stress set, 1,048,576 problems")
 
 
 def test_five_million_problems_ragged(oracle):
@@ -168,3 +178,47 @@ def test_five_million_problems_ragged(oracle):
         it_o, _ = oracle.batch_solve_gated(3, aos, 1e-8, 200)
         ok = keep_mask(len(it_o), certify_iteration_counts(oracle, 3, init, it[sl], it_o, 1e-8))
         assert serr(st[sl, :3][ok], aos[ok, :3]) < 1e-10
+
+
+def test_config4_eight_million_problems_as_eight_shards_on_one_device(oracle):
+    # BASELINE configs[3]: 8,388,608 F3 problems in contiguous shards of 1,048,576 -- one per GPU of the node there;
+    # here the eight shards run one after the other on the one device.  Each shard generates its own slice of the job's problems,
+    # solves it (gated, fused) and reduces it; the eight summaries reduce (MAX, MAX, SUM, SUM -- what the one RCCL all-reduce of
+    # the path does, sharding.py) to the summary of the WHOLE job solved as one batch; two shards meet the oracle in full, the
+    # others on their device-side solution records and a range read-back.
+    from hip_util import DeviceBuffer
+    shards, per = 8, 1 << 20
+    n = shards * per
+    g = [0.0, -np.inf, 0.0, 0.0]
+    recs = []
+    with rp.Batch(per) as b, DeviceBuffer(32 * per) as out:
+        b.bind_solution(out.ptr)
+        for s in range(shards):
+            first, count = rp.problems.shard_range(n, s, shards)
+            assert (first, count) == (s * per, per)
+            q0, q1, q2 = rp.problems.generate(12345, first, count, rp.problems.DIST_MONOTONE)
+            b.set_problems(q0, q1, q2)
+            b.solve(1e-8, 200, 0)
+            rs = b.reduce()
+            rec = out.read(np.dtype(rp.capi.SOLUTION_FIELDS))
+            assert np.all(rec["status"] == rp.ST_CONVERGED) and rs["n_converged"] == per and rs["total_steps"] == float(rec["iters"].sum())
+            assert np.array_equal(b.get_state_range(777, 64)[:, :3], np.stack([rec["vel1"], rec["duration0"], rec["duration1"]], axis=1)[777:841])
+            if s in (0, 5):
+                st = b.get_state()
+                assert np.array_equal(st[:, 0], rec["vel1"]) and np.array_equal(st[:, 2], rec["duration1"])
+                _whole_batch_against_the_oracle(oracle, q0, q1, q2, rec["iters"], st, "configs[3] shard %d of 8" % s)
+            g = [max(g[0], rs["max_residual_sq"]), max(g[1], rs["max_gap"]), g[2] + rs["n_converged"], g[3] + rs["total_steps"]]
+            recs.append((rec["iters"].astype(np.int64).sum(), float(rec["duration0"].sum()), float(rec["vel1"][12345])))
+    # the whole job as ONE batch of 8,388,608 problems: same summary, same per-shard sums
+    p0, p1, p2 = rp.problems.generate(12345, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as whole, DeviceBuffer(32 * n) as out:
+        whole.bind_solution(out.ptr)
+        whole.set_problems(p0, p1, p2)
+        whole.solve(1e-8, 200, 0)
+        r = whole.reduce()
+        rec = out.read(np.dtype(rp.capi.SOLUTION_FIELDS))
+    assert g == [r["max_residual_sq"], r["max_gap"], r["n_converged"], r["total_steps"]] and r["n_converged"] == n
+    for s in range(shards):
+        sl = slice(s * per, (s + 1) * per)
+        assert recs[s] == (rec["iters"][sl].astype(np.int64).sum(), float(rec["duration0"][sl].sum()), float(rec["vel1"][s * per + 12345]))
+    print("configs[3]: 8 shards of 1,048,576 on one device: %.0f steps, all %d converged, max gap %.3e; summaries reduce to the whole batch's" % (g[3], n, g[1]))

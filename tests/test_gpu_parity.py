@@ -1002,3 +1002,152 @@ def test_f4_wave_parallel_line_search_equals_single_steps_bitwise(dtype):
         assert np.array_equal(a.get_state(), b.get_state())
         assert np.all(a.get_iters()[0] == 36)
         assert (nr > 20).sum() > 30, (nr > 20).sum()      # ... so the service did run on the other side (fp64: ~1 % of the problems, fp32: a few dozen)
+
+
+# ---------------------------------------------------------------- round 4: sweeps that were hand-run scripts, now in the suite
+def test_fuzz_131072_fresh_gated_solves_against_the_oracle(oracle):
+    # tests/checks/fuzz_parity.py (1.44 M solves, hand-run) in suite size: 131,072 fresh problems of each distribution, a seed no
+    # other test uses -- iteration counts (certified ties printed), (v, t0, t1) at 1e-10, multipliers where they are determined,
+    # and 12 ungated steps of the same problems
+    n = 131072
+    ties_total = 0
+    with rp.Batch(n) as b:
+        for dist in (rp.problems.DIST_MONOTONE, rp.problems.DIST_REFERENCE_LIKE, rp.problems.DIST_NON_MONOTONE):
+            p0, p1, p2 = rp.problems.generate(70_000_133 + 1_000_003 * dist, 0, n, dist)
+            init = oracle.batch_init_feasible(3, p0, p1, p2)
+            ref = init.copy()
+            it_o, _ = oracle.batch_solve_gated(3, ref, 1e-8, 200, threads=0)
+            b.set_problems(p0, p1, p2)
+            b.solve(1e-8, 200, 0)
+            it_g, st = b.get_iters()
+            x = b.get_state()
+            ties = certify_iteration_counts(oracle, 3, init, it_g, it_o, 1e-8, max_ties=3)
+            ok = keep_mask(n, ties)
+            ties_total += len(ties)
+            assert np.all(st == rp.ST_CONVERGED)
+            assert serr(x[ok, :3], ref[ok, :3]) < TOL
+            assert lam_err(x[ok, 3:11], ref[ok, 3:11]) < (LAM_TOL_DEGENERATE if dist == rp.problems.DIST_NON_MONOTONE else LAM_TOL)
+            fx = init.copy()
+            oracle.batch_steps(3, fx, 12, threads=0)
+            b.restart()
+            b.step(12)
+            assert serr(b.get_state()[:, :3], fx[:, :3]) < TOL
+    print("fuzz: 3 x %d fresh solves, %d certified gate tie(s), 0 other iteration mismatches" % (n, ties_total))
+
+
+@pytest.mark.parametrize("dtype", [rp.DTYPE_F64, rp.DTYPE_F32_STATE])
+def test_f4_feasibility_decisions_step_by_step_from_the_oracles_states(oracle, dtype):
+    # tests/checks/f4_screen_check.py in suite size: 10 steps (steps 18..27 of the oracle's trajectories, where half of the problems
+    # sit in a sequence of 10-19 feasibility halvings) of 4,096 problems, the device re-started from the ORACLE's state before every
+    # step (F4 is chaotic).  The stepping launch (k_newton_stream16, with the closed-form ray proof and the per-trial proof) must
+    # equal the counted launch (k_newton_counted: in double arithmetic it has NEITHER proof -- every trial is evaluated) bit for
+    # bit, and the counted launch's feasibility halvings must be the oracle's, problem by problem.
+    n, first_step, steps = 4096, 18, 10
+    p0, p1, p2 = rp.problems.generate(31415, 0, n, rp.problems.DIST_MONOTONE)
+    aos = oracle.batch_init_feasible(rp.VARIANT_F4, p0, p1, p2)
+    oracle.batch_steps(rp.VARIANT_F4, aos, first_step, threads=0)
+    info = StepInfo()
+    tot_f = long_seq = bad_f = bad_r = 0
+    with rp.Batch(n, rp.VARIANT_F4, dtype) as a, rp.Batch(n, rp.VARIANT_F4, dtype) as b:
+        for s in range(steps):
+            if dtype != rp.DTYPE_F64:
+                aos[:] = aos.astype(np.float32).astype(np.float64)      # what the batch will hold (state and constants)
+            a.set_state(aos)
+            b.set_state(aos)
+            nf, nr = a.step_counted(1)
+            b.step(1)
+            assert np.array_equal(a.get_state(), b.get_state()), s       # proofs on == every trial evaluated
+            for i in range(n):
+                oracle.step(rp.VARIANT_F4, aos[i], info)
+                tot_f += info.feas_halvings
+                long_seq += int(info.feas_halvings >= 10)
+                bad_f += int(nf[i] != info.feas_halvings)
+                bad_r += int(nr[i] != info.resid_halvings)
+    print("F4 dtype %d: %d problem-steps, %d feasibility halvings, %d sequences of ten or more; feasibility counts that differ: %d, residual: %d"
+          % (dtype, n * steps, tot_f, long_seq, bad_f, bad_r))
+    assert long_seq > n * steps // 8 and bad_f == 0
+    assert bad_r <= n * steps // 100                                     # last-bit decisions of stalled problems, as in the tests above
+
+
+@pytest.mark.parametrize("dtype", [rp.DTYPE_F64, rp.DTYPE_F32_STATE, rp.DTYPE_F32])
+def test_f4_steps_from_points_that_are_infeasible_beyond_doubt(oracle, dtype):
+    # the closed-form count of proven feasibility halvings (skip_certain_halvings) bisects over "g(s 2^-k) > 0", which is
+    # monotone in k only if g(0) <= 0 or g is concave.  From a point x that is ITSELF beyond doubt infeasible (a nudge, a set
+    # state, an RP_ST_INFEASIBLE start) a convex g can be positive at s, negative in between and positive again near 0: the
+    # bisection then "proved" all 100 halvings where the reference halves once or twice and moves.  Starts with zero end
+    # velocities (the instantiations that carry the proofs), pushed outside: durations shortened, velocities spread.
+    n = 8192
+    rng = np.random.RandomState(77)
+    p0, p1, p2 = rp.problems.generate(1234, 0, n, rp.problems.DIST_MONOTONE)
+    aos = oracle.batch_init_feasible(rp.VARIANT_F4, p0, p1, p2)
+    aos[:, 1] *= rng.uniform(0.55, 1.0, n)
+    aos[:, 2] *= rng.uniform(0.55, 1.0, n)
+    aos[:, 0] = rng.uniform(-120, 260, n)
+    aos[0, :3] = (190.0, 2.4, aos[0, 2])                                 # the advisor's example: g = 10 - 140 s + 200 s^2 along (dv, d0) = (-150, 1)
+    if dtype != rp.DTYPE_F64:
+        aos[:] = aos.astype(np.float32).astype(np.float64)
+    outside = np.array([not oracle.satisfied(rp.VARIANT_F4, row) for row in aos])
+    assert outside.sum() > n // 2
+    info = StepInfo()
+    exp = aos.copy()
+    of = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        oracle.step(rp.VARIANT_F4, exp[i], info)
+        of[i] = info.feas_halvings
+    with rp.Batch(n, rp.VARIANT_F4, dtype) as a, rp.Batch(n, rp.VARIANT_F4, dtype) as b, rp.Batch(n, rp.VARIANT_F4, dtype) as c:
+        a.set_state(aos)
+        b.set_state(aos)
+        c.set_state(aos)
+        nf, _ = a.step_counted(1)
+        b.step(1)                                                        # k_newton_stream16, ZV: ray proof + per-trial proof
+        c.step(2)                                                        # k_steps_chunks: the same proofs in the fused launch
+        b1 = b.get_state()
+        b.step(1)
+        assert np.array_equal(c.get_state(), b.get_state())
+        if dtype != rp.DTYPE_F32:
+            # double arithmetic: the counted launch evaluates every trial; the stepping launch must agree bit for bit, and the
+            # feasibility counts are the oracle's (fp32 state: the oracle steps from the same fp32-representable point)
+            assert np.array_equal(a.get_state(), b1)
+            assert np.array_equal(nf, of), "%d feasibility counts differ" % int((nf != of).sum())
+        else:
+            # single precision decides a borderline trial differently now and then, never by much: no step may collapse to
+            # s 2^-100 where the reference moves
+            assert np.mean(nf == of) > 0.97 and np.max(np.abs(nf.astype(np.int64) - of)[of < 90]) <= 3
+    # where the reference's step moves the point, so does the device's (a step that collapsed to s 2^-100 leaves x where it was)
+    moved = np.abs(exp[:, :3] - aos[:, :3]).max(axis=1) > 1e-9
+    got_moved = np.abs(b1[:, :3] - aos[:, :3]).max(axis=1) > 1e-9
+    assert moved.sum() > n // 2
+    assert np.mean(moved == got_moved) > (0.99 if dtype == rp.DTYPE_F32 else 0.9999), np.mean(moved == got_moved)
+
+
+@pytest.mark.parametrize("variant,dtype", [(rp.VARIANT_F3, rp.DTYPE_F64), (rp.VARIANT_F4, rp.DTYPE_F64)])
+@pytest.mark.parametrize("backtrack,max_bt", [(0.5, 0), (0.5, 1), (0.5, 3), (0.25, 40), (0.75, 7), (0.5, 100)])
+def test_gated_kernel_steps_with_other_line_search_constants_against_the_oracle(oracle, variant, dtype, backtrack, max_bt):
+    # the in-place step of the gated kernel (newton_step_inplace) under non-default rp_params -- budgets of 0, 1
+    # and 3 halvings, other backtrack factors -- against the oracle taking the same constants (orc_step_params; (0.5, 100) is the
+    # reference).  A gate that never closes (tolerance -1: no gap is below it) makes the gated launch take exactly k steps.
+    n, k = 4096 + 37, 6
+    p0, p1, p2 = rp.problems.generate(97, 0, n, rp.problems.DIST_MONOTONE)
+    exp = oracle.batch_init_feasible(variant, p0, p1, p2)
+    oracle.batch_steps_params(variant, exp, k, backtrack, max_bt, threads=0)
+    with rp.Batch(n, variant, dtype) as g, rp.Batch(n, variant, dtype) as f:
+        for b in (g, f):
+            b.set_params(backtrack=backtrack, max_backtracks=max_bt)
+            b.set_problems(p0, p1, p2)
+        g.solve(-1.0, k, 0)                          # k gated steps through k_solve_chunks<START>
+        f.step(k)                                    # the fixed-step kernel
+        sg, sf = g.get_state(), f.get_state()
+        it, status = g.get_iters()
+    assert np.all(it == k) and np.all((status & rp.ST_MAXITER) != 0)
+    fin = np.all(np.isfinite(exp[:, :3]), axis=1)
+    assert fin.mean() > 0.99
+    # a budget of 0-3 halvings lets iterates leave the feasible set (the reference would, too): from there on a step is as
+    # ill-conditioned as the point is far outside, and F4 is chaotic anyway -- the tight bound is for the well-posed cases
+    tol = TOL if (variant == rp.VARIANT_F3 and max_bt >= 40) else 1e-6
+    eg = np.abs(sg[fin, :3] - exp[fin, :3]) / np.maximum(np.abs(exp[fin, :3]), 1.0)
+    ef = np.abs(sf[fin, :3] - exp[fin, :3]) / np.maximum(np.abs(exp[fin, :3]), 1.0)
+    print("variant %d backtrack %g budget %d: gated kernel worst %.2e (median %.1e), fixed-step kernel worst %.2e" % (
+        variant, backtrack, max_bt, np.nanmax(eg), np.nanmedian(eg), np.nanmax(ef)))
+    assert np.nanquantile(eg, 0.99) < tol and np.nanquantile(ef, 0.99) < tol
+    if variant == rp.VARIANT_F3 and max_bt >= 40:
+        assert np.nanmax(eg) < TOL and np.nanmax(ef) < TOL
