@@ -27,7 +27,8 @@ def one(d, pat):
     return max(glob.glob(os.path.join(d, "*", pat)), key=os.path.getmtime)
 
 
-shutil.copy(one(stats_dir, "*_kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_kernel_stats.csv" % tag))
+if stats_dir != "-":      # "-": the counter summaries only (collect_r4.sh folds them before the kernel-trace pass, which needs them)
+    shutil.copy(one(stats_dir, "*_kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_kernel_stats.csv" % tag))
 
 
 def counters(d, grid=None):

@@ -910,7 +910,11 @@ __device__ __forceinline__ int skip_certain_halvings(const P &k, const KParams<T
                 // out of halvings -- but NOT for a convex one, which may dip below zero in between (10 - 140 s + 200 s^2): there the
                 // closed form is not used and the per-trial proof below, sequential and always sound, walks the trials.
                 // Seven probes find the last true k in [0, 127]; every counted halving lies between two EVALUATED positives.
+#ifdef RP_RAY_ASSUME_MONOTONE      // the round-3 form, for showing that tests/test_gpu_parity.py::test_f4_steps_from_points_that_are_infeasible_beyond_doubt bites
+                const bool monotone = true;
+#else
                 const bool monotone = !(ray.g0 > T(0)) || !(ray.g2 > T(0));
+#endif
                 int last = 0;
 #pragma unroll
                 for (int b = 64; b >= 1; b >>= 1) last += ray.holds(ldexp_(s, -(last + b))) ? b : 0;

@@ -84,8 +84,13 @@ __device__ __forceinline__ void store_solution(Solution *rec, double v, double t
     const unsigned long long words = ((unsigned long long)st << 32) | (unsigned long long)(uint32_t)it;      // little endian: iters, then status
     const v2 a = {v, t0}, b = {t1, __longlong_as_double((long long)words)};
     v2 *dst = reinterpret_cast<v2 *>(rec);
+#ifdef RP_SOLUTION_NT
     __builtin_nontemporal_store(a, dst);
     __builtin_nontemporal_store(b, dst + 1);
+#else
+    dst[0] = a;      // plain stores: the two halves of the sector meet in L2 and leave it as one write -- 29.5 us per 1 Mi records
+    dst[1] = b;      // where nontemporal stores take 79 us and a gather through slot_of 46 us (profiles/r4_solution_probe.log)
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -810,7 +815,7 @@ k_soa_to_aos_rows(const T *__restrict__ base, size_t stride, size_t n, const uin
     __syncthreads();
     for (size_t j = threadIdx.x; j < rows * M; j += kBlock) {
         const size_t r = j / M, f = j % M;
-        __builtin_nontemporal_store(tile[r * (M + 1) + f], aos + (size_t)s_prob[r] * M + f);
+        aos[(size_t)s_prob[r] * M + f] = tile[r * (M + 1) + f];      // plain stores: the 8-byte pieces of a sector meet in L2 (nontemporal ones do not: profiles/r4_solution_probe.log)
     }
 }
 
@@ -849,6 +854,18 @@ k_solution(const S *__restrict__ base, size_t stride, size_t n, const int32_t *_
     const size_t prob = prob_of ? (size_t)prob_of[s] : s;
     store_solution(out + prob, (double)ld_once(base + s), (double)ld_once(base + stride + s), (double)ld_once(base + 2 * stride + s),
                    iters[s] + iters_add, status[s]);
+}
+
+// the same walking PROBLEMS: five gathered sectors read per problem, records written coalesced (A/B form, -DRP_SOLUTION_GATHER)
+template <typename S>
+__global__ void __launch_bounds__(kBlock)
+k_solution_gather(const S *__restrict__ base, size_t stride, size_t n, const int32_t *__restrict__ iters, const uint32_t *__restrict__ status,
+                  const uint32_t *__restrict__ slot_of, int iters_add, Solution *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const size_t s = slot_of[i];
+    store_solution(out + i, (double)base[s], (double)base[stride + s], (double)base[2 * stride + s], iters[s] + iters_add, status[s]);
 }
 
 // Feasible start (build-defined): vel1 = 0, t_i = (3.5/sqrt 12) sqrt(6 |dX_i| / L), multipliers 1,
@@ -1250,6 +1267,13 @@ hipError_t launch_solution(const BatchView &b, Solution *d_out, hipStream_t stre
 {
     if (b.n == 0) return hipSuccess;
     const uint32_t *inv = b.scheduled ? (const uint32_t *)b.prob_of : nullptr;
+#ifdef RP_SOLUTION_GATHER
+    if (b.scheduled) {
+        if (b.dtype == 0) hipLaunchKernelGGL((k_solution_gather<double>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream, (const double *)b.base, b.stride, b.n, b.iters, b.status, (const uint32_t *)b.slot_of, b.iters_add, d_out);
+        else              hipLaunchKernelGGL((k_solution_gather<float>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream, (const float *)b.base, b.stride, b.n, b.iters, b.status, (const uint32_t *)b.slot_of, b.iters_add, d_out);
+        return hipGetLastError();
+    }
+#endif
     if (b.dtype == 0) hipLaunchKernelGGL((k_solution<double>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream, (const double *)b.base, b.stride, b.n, b.iters, b.status, inv, b.iters_add, d_out);
     else              hipLaunchKernelGGL((k_solution<float>), dim3(grid_for(b.n)), dim3(kBlock), 0, stream, (const float *)b.base, b.stride, b.n, b.iters, b.status, inv, b.iters_add, d_out);
     return hipGetLastError();

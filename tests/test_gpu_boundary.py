@@ -546,11 +546,11 @@ def test_a_limit_changed_after_set_problems_does_not_move_the_start():
         a.set_problems(p0, p1, p2)
         start = a.get_state()
         b.set_problems(p0, p1, p2)
-        b.set_params(accel_limit=50.0)              # before anything has touched the state
+        b.set_params(accel_limit=150.0)             # before anything has touched the state
         assert np.array_equal(b.get_state(), start)
         b.solve(1e-8, 200, 0)
         _, acc = b.sample()
-        assert 49.99 < np.max(np.abs(acc)) <= 50.0 * (1 + 1e-9)      # ... while the solve obeys the new limit
+        assert 149.99 < np.max(np.abs(acc)) <= 150.0 * (1 + 1e-9)    # ... while the solve obeys the new limit
         b.restart()                                 # a restart asked for NOW uses the limit of now
         assert not np.array_equal(b.get_state()[:, 1:3], start[:, 1:3])
 
