@@ -878,6 +878,98 @@ struct HalvingDiag {
     __device__ __forceinline__ void moving() { ++nm; }
 };
 
+// The residual at a FIXED point x as a function of the step length (the reference's post-convergence regime: the trial point
+// x + s dx has become x bit for bit and only the multipliers lam + s dl still move).  Every component of the residual vector is
+// then affine in s, r_i(0) + s r_i': the pieces are formed once per step and a halving is 11 multiply-adds for the components
+// plus the sum of squares, in residual_norm's order -- so that once s r_i' drops below half an ulp the value is the value at
+// s = 0 bit for bit, which is what ends the reference's loop after ~48 halvings (onedpath_ip.cpp:941).
+// lam_at(i): the multipliers the step starts from (registers, or the in-place step's LDS column).
+template <typename T, int VARIANT> struct AffineResidual {
+    static constexpr int NC = CMap<VARIANT>::NC;
+    T rv0, rv1, ra0, ra1, rb0, rb1, c0[NC], c1[NC];
+    template <class LamAt>
+    __device__ __forceinline__ void setup(const Acc<T> &et, LamAt lam_at, const T (&dl)[NC], T p, T L)
+    {
+        rv0 = T(0); rv1 = T(0); ra0 = T(1); ra1 = T(0); rb0 = T(1); rb1 = T(0);
+        if constexpr (VARIANT == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const T lm = lam_at(2 * q), lp = lam_at(2 * q + 1);
+                const T d0 = lp - lm, d1 = dl[2 * q + 1] - dl[2 * q];
+                rv0 = fma_(d0, acc_gv(et, q), rv0);
+                rv1 = fma_(d1, acc_gv(et, q), rv1);
+                if (q < 2) { ra0 = fma_(d0, et.gt[q], ra0); ra1 = fma_(d1, et.gt[q], ra1); }
+                else       { rb0 = fma_(d0, et.gt[q], rb0); rb1 = fma_(d1, et.gt[q], rb1); }
+                const T cm = -et.a[q] - L, cp = et.a[q] - L;
+                c0[2 * q] = fma_(lm, cm, p);
+                c1[2 * q] = dl[2 * q] * cm;
+                c0[2 * q + 1] = fma_(lp, cp, p);
+                c1[2 * q + 1] = dl[2 * q + 1] * cp;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                T gv, gt;
+                c_grad<T, 4>(i, et, gv, gt);
+                const T li = lam_at(i);
+                rv0 = fma_(li, gv, rv0);
+                rv1 = fma_(dl[i], gv, rv1);
+                if (i < 2) { ra0 = fma_(li, gt, ra0); ra1 = fma_(dl[i], gt, ra1); }
+                else       { rb0 = fma_(li, gt, rb0); rb1 = fma_(dl[i], gt, rb1); }
+                const T ci = c_value<T, 4>(i, et, L);
+                c0[i] = fma_(li, ci, p);
+                c1[i] = dl[i] * ci;
+            }
+        }
+    }
+    __device__ __forceinline__ T operator()(T sq) const
+    {
+        T accm = T(0), accp = T(0);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const T ri = fma_(c1[i], sq, c0[i]);
+            if (i & 1) accp = fma_(ri, ri, accp);
+            else       accm = fma_(ri, ri, accm);
+        }
+        const T rv = fma_(rv1, sq, rv0), ra = fma_(ra1, sq, ra0), rb = fma_(rb1, sq, rb0);
+        return (accm + accp) + fma_(rb, rb, fma_(ra, ra, rv * rv));
+    }
+    // The reference's loop from trial number `it` on (s is that trial's step length, not yet tested): W step lengths per trip
+    // (s and its next W - 1 halvings), accepted in the reference's order.  A lone wave on its SIMD is bound by the latency of
+    // one evaluation's dependent chain; all W evaluations are complete before the one branch of the trip, so they fill each
+    // other's gaps.  r0: the residual the trials have to beat.  Returns whether a trial was accepted.
+    template <class D>
+    __device__ __forceinline__ bool search(const KParams<T> &kp, T r0, T &s, int &it, D &diag) const
+    {
+        constexpr int W = 2;      // measured at 65,536 problems x 50 steps: W = 1 0.545 ms, W = 2 0.332 ms, W = 4 0.352 ms
+        while (it < kp.max_bt) {
+            T sk[W], rn[W];
+            sk[0] = s;
+#pragma unroll
+            for (int q = 1; q < W; ++q) sk[q] = sk[q - 1] * kp.backtrack;
+#pragma unroll
+            for (int q = 0; q < W; ++q) rn[q] = (*this)(sk[q]);
+            const int valid = (kp.max_bt - it < W) ? kp.max_bt - it : W;      // trials the reference would still make
+            int first = W;                                                    // first accepted trial of this trip
+#pragma unroll
+            for (int q = W - 1; q >= 0; --q)
+                if (q < valid && rn[q] <= r0 * (T(1) - kp.armijo * sk[q])) first = q;
+            const bool got = first < W;
+            const int halved = got ? first : valid;
+            T snew = sk[W - 1] * kp.backtrack;                                // all W failed
+#pragma unroll
+            for (int q = W - 1; q >= 0; --q)
+                if (halved == q) snew = sk[q];
+            s = snew;
+            if constexpr (!std::is_same<D, NoDiag>::value)
+                for (int q = 0; q < halved; ++q) diag.resid();
+            it += halved;
+            if (got) return true;
+        }
+        return false;
+    }
+};
+
 #ifndef RP_FEAS_SCREEN
 #define RP_FEAS_SCREEN 1      // F4: walk the feasibility loop past trials that are infeasible beyond doubt (0: evaluate every trial, for A/B runs)
 #endif
@@ -1277,82 +1369,10 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
                     diag.resid();
                 }
             } else {
-            // With x fixed the residual vector is AFFINE in s: every component is r_i(0) + s r_i'.  The pieces are formed
-            // once per step; a halving is then 11 multiply-adds for the components and the same sum of squares, in the same
-            // order, as residual_norm -- so that once s r_i' drops below half an ulp the loop sees r(x) bit for bit, as the
-            // direct evaluation does (that is what ends the reference's loop after ~48 halvings, onedpath_ip.cpp:941).
-            T rv0 = T(0), rv1 = T(0), ra0 = T(1), ra1 = T(0), rb0 = T(1), rb1 = T(0);
-            T c0[NC], c1[NC];
-            if constexpr (VARIANT == 3) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const T d0 = lam[2 * q + 1] - lam[2 * q], d1 = dl[2 * q + 1] - dl[2 * q];
-                    rv0 = fma_(d0, acc_gv(et, q), rv0);
-                    rv1 = fma_(d1, acc_gv(et, q), rv1);
-                    if (q < 2) { ra0 = fma_(d0, et.gt[q], ra0); ra1 = fma_(d1, et.gt[q], ra1); }
-                    else       { rb0 = fma_(d0, et.gt[q], rb0); rb1 = fma_(d1, et.gt[q], rb1); }
-                    const T cm = -et.a[q] - L, cp = et.a[q] - L;
-                    c0[2 * q] = fma_(lam[2 * q], cm, p);
-                    c1[2 * q] = dl[2 * q] * cm;
-                    c0[2 * q + 1] = fma_(lam[2 * q + 1], cp, p);
-                    c1[2 * q + 1] = dl[2 * q + 1] * cp;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    T gv, gt;
-                    c_grad<T, 4>(i, et, gv, gt);
-                    rv0 = fma_(lam[i], gv, rv0);
-                    rv1 = fma_(dl[i], gv, rv1);
-                    if (i < 2) { ra0 = fma_(lam[i], gt, ra0); ra1 = fma_(dl[i], gt, ra1); }
-                    else       { rb0 = fma_(lam[i], gt, rb0); rb1 = fma_(dl[i], gt, rb1); }
-                    const T ci = c_value<T, 4>(i, et, L);
-                    c0[i] = fma_(lam[i], ci, p);
-                    c1[i] = dl[i] * ci;
-                }
-            }
-            auto affine_rn = [&](T sq) -> T {
-                T accm = T(0), accp = T(0);
-#pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const T ri = fma_(c1[i], sq, c0[i]);
-                    if (i & 1) accp = fma_(ri, ri, accp);
-                    else       accm = fma_(ri, ri, accm);
-                }
-                const T rv = fma_(rv1, sq, rv0), ra = fma_(ra1, sq, ra0), rb = fma_(rb1, sq, rb0);
-                return (accm + accp) + fma_(rb, rb, fma_(ra, ra, rv * rv));
-            };
-            // W step lengths per trip (s and its next W - 1 halvings), accepted in the reference's order.  A lone wave on its
-            // SIMD is bound by the latency of one evaluation's dependent chain; all W evaluations are complete before the
-            // one branch of the trip, so they fill each other's gaps.
-            constexpr int W = 2;      // measured at 65,536 problems x 50 steps: W = 1 0.545 ms, W = 2 0.332 ms, W = 4 0.352 ms
-            while (it < kp.max_bt) {
-                T sk[W], rn[W];
-                sk[0] = s;
-#pragma unroll
-                for (int q = 1; q < W; ++q) sk[q] = sk[q - 1] * kp.backtrack;
-#pragma unroll
-                for (int q = 0; q < W; ++q) rn[q] = affine_rn(sk[q]);
-                const int valid = (kp.max_bt - it < W) ? kp.max_bt - it : W;      // trials the reference would still make
-                int first = W;                                                    // first accepted trial of this trip
-#pragma unroll
-                for (int q = W - 1; q >= 0; --q)
-                    if (q < valid && rn[q] <= r0n * (T(1) - kp.armijo * sk[q])) first = q;
-                const bool got = first < W;
-                const int halved = got ? first : valid;
-                T snew = sk[W - 1] * kp.backtrack;                                // all W failed
-#pragma unroll
-                for (int q = W - 1; q >= 0; --q)
-                    if (halved == q) snew = sk[q];
-                s = snew;
-                if constexpr (!std::is_same<D, NoDiag>::value)
-                    for (int q = 0; q < halved; ++q) diag.resid();
-                it += halved;
-                if (got) {
-                    accepted = true;
-                    break;
-                }
-            }
+            // With x fixed the residual vector is AFFINE in s (AffineResidual above): pieces once per step, 27 instructions per halving
+            AffineResidual<T, VARIANT> ar;
+            ar.setup(et, [&](int i) { return lam[i]; }, dl, p, L);
+            accepted = ar.search(kp, r0n, s, it, diag);
             }
         }
     }
@@ -1427,9 +1447,18 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 // is a multiply-add INTO the state registers.
 template <typename T> using LdsBackup = __attribute__((address_space(3))) volatile T *;      // LDS address space kept in the type: ds_read / ds_write, not flat accesses
 
-template <typename T, int VARIANT, class P>
+// FROZEN (the fixed-step kernels: a gated solve stops long before): the reference's post-convergence regime, where x no longer
+// moves and every step still walks ~48 residual halvings (onedpath_ip.cpp:932-945), gets its own search -- see "frozen" below.
+// D: line-search bookkeeping (rp_batch_step_counted).
+//
+// Loop shape: a loop's exit test is a ballot over a COMPARISON made in the same block ("some lane's trial failed"), not over a
+// flag carried round the loop -- the flag form costs a select and a compare per test to turn the carried bit back into a lane
+// mask; a lane whose trial has passed simply re-evaluates its unchanged trial (same values, the instructions issue for the wave
+// anyway) while others retry.  The halving counter `it` is touched only where a trial fails: it enters every loop as zero and is
+// put back to zero behind a wave-uniform branch when some lane used it.
+template <typename T, int VARIANT, class P, bool FROZEN = false, class D = NoDiag>
 __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T> &kp, T gap, T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
-                                                    AccCarry<T, true, true> &c, LdsBackup<T> bk)
+                                                    AccCarry<T, true, true> &c, LdsBackup<T> bk, int &it, D &diag)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     const T L = kp.limit;
@@ -1452,65 +1481,122 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
 
     T s = boundary_fraction<T, NC>(kp, lam, dl, sg, suspect);         // onedpath_ip.cpp:903-915
 
-    // Both loops are WAVE-UNIFORM: they run while any lane is still searching, a lane that is done sits out under the
-    // execution mask.  (A loop that lanes leave one by one makes the compiler copy every value that is live after it -- the
-    // state -- at every trip, for the lanes that have left: the 11 moves per step this form is there to avoid.)
     // -- backtrack until primal feasible (onedpath_ip.cpp:919-928); a trial is formed where s is set --
     Acc<T> et;
     T u0, u1;      // dX / t of the trial point et belongs to
-    NoDiag none;
-    const int it_feas = skip_certain_halvings<T, VARIANT, P, NoDiag>(k, kp, L, v, t0, t1, dxv, dx0, dx1, s, none);      // (F4: its certain halvings)
+    if constexpr (VARIANT == 4) it = skip_certain_halvings<T, VARIANT, P, D>(k, kp, L, v, t0, t1, dxv, dx0, dx1, s, diag);      // (F4: its certain halvings)
     v = fma_(dxv, s, v);
     t0 = fma_(dx0, s, t0);
     t1 = fma_(dx1, s, t1);
     {
-        bool open = true;
-        int it = it_feas;
-        do {
-            if (open) {
-                accel_values_u(k, v, t0, t1, et, u0, u1);
-                if (all_satisfied<T, VARIANT>(et, L) || !(it < kp.max_bt)) {      // (out of halvings: the reference goes on with an s it has not tested)
-                    open = false;
+        bool used = VARIANT == 4;      // wave-uniform: some lane has moved its counter
+        [[maybe_unused]] bool at_x = false;      // FROZEN: the trial point has become x itself (and every later one will be)
+        for (;;) {
+            accel_values_u(k, v, t0, t1, et, u0, u1);
+            const bool bad = !all_satisfied<T, VARIANT>(et, L);
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+            // (out of halvings: the reference goes on with an s it has not tested)
+            const bool again = bad && it < kp.max_bt;
+            if (__builtin_amdgcn_ballot_w64(again) == 0ull) break;
+            used = true;
+            if (again) {
+                if (FROZEN && at_x) {
+                    // x itself fails the test by a rounding (the residual loop accepts points the feasibility loop never saw, as the
+                    // reference's does) and every smaller s gives x again: the reference walks its remaining halvings to the same
+                    // verdict.  So does this, without the evaluations.
+                    if (kp.backtrack == T(0.5) && std::is_same<D, NoDiag>::value) {
+                        s = ldexp_(s, it - kp.max_bt);
+                    } else {
+                        for (int q = it; q < kp.max_bt; ++q) { s *= kp.backtrack; diag.feas(); }
+                    }
+                    it = kp.max_bt;
                 } else {
                     s *= kp.backtrack;
                     ++it;
-                    v = fma_(dxv, s, bk[0 * 64]);
-                    t0 = fma_(dx0, s, bk[1 * 64]);
-                    t1 = fma_(dx1, s, bk[2 * 64]);
+                    diag.feas();
+                    const T x0 = bk[0 * 64], x1 = bk[1 * 64], x2 = bk[2 * 64];
+                    v = fma_(dxv, s, x0);
+                    t0 = fma_(dx0, s, x1);
+                    t1 = fma_(dx1, s, x2);
+                    if constexpr (FROZEN) at_x = v == x0 && t0 == x1 && t1 == x2;
                 }
             }
-        } while (__builtin_amdgcn_ballot_w64(open) != 0ull);
+        }
+        if (used) it = 0;
     }
     // -- backtrack until the residual decreases (onedpath_ip.cpp:932-945), and take the step (:949-952): the trial that ends
     // the loop -- accepted, or the last s, which the reference takes untested -- is the new state, its sums the next step's --
+#pragma unroll
+    for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
     {
-        bool open = true;
-        int it = 0;
-        do {
-            if (open) {
-                accel_grads_u(k, v, et, u0, u1);
+        bool used = false;
+        [[maybe_unused]] bool frozen = false;      // FROZEN: the trial point has become bitwise x (and stays so: s only shrinks)
+        for (;;) {
+            accel_grads_u(k, v, et, u0, u1);
+            residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);      // (r0n and the direction have taken what they needed from c)
+            const T rn = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
+            diag.moving();
+            const bool bad = !(rn <= r0n * (T(1) - kp.armijo * s));
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+            const bool again = bad && it < kp.max_bt && !(FROZEN && frozen);
+            if (__builtin_amdgcn_ballot_w64(again) == 0ull) break;
+            used = true;
+            if (again) {
+                s *= kp.backtrack;
+                ++it;
+                diag.resid();
+                // (all eleven reads are issued before the first use: the multipliers arrive under the trial point's evaluation)
+                const T x0 = bk[0 * 64], x1 = bk[1 * 64], x2 = bk[2 * 64];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) lam[i] = bk[(3 + i) * 64];
+                v = fma_(dxv, s, x0);
+                t0 = fma_(dx0, s, x1);
+                t1 = fma_(dx1, s, x2);
+                if constexpr (FROZEN) frozen = v == x0 && t0 == x1 && t1 == x2;
+                accel_values_u(k, v, t0, t1, et, u0, u1);
 #pragma unroll
                 for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
-                residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);      // (r0n and the direction have taken what they needed from c)
-                const T rn = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
-                if (rn <= r0n * (T(1) - kp.armijo * s) || !(it < kp.max_bt)) {
-                    open = false;
-                } else {
-                    s *= kp.backtrack;
-                    ++it;
-                    v = fma_(dxv, s, bk[0 * 64]);
-                    t0 = fma_(dx0, s, bk[1 * 64]);
-                    t1 = fma_(dx1, s, bk[2 * 64]);
+            }
+            // FROZEN: when every lane that is still searching has frozen, the affine search below takes over at once (its first
+            // candidate is the trial just formed); the sums of such a trial are only wanted for the one the search ends on
+            if constexpr (FROZEN) {
+                if (__builtin_amdgcn_ballot_w64(again && !frozen) == 0ull) break;
+            }
+        }
+        if constexpr (FROZEN) {
+            // ---- frozen: x + s dx == x from here on ----
+            // The evaluation of the point is loop-invariant (et, formed above from the very bits of x); only the multipliers
+            // lam + s dl still depend on s.  The rest of the search runs on the affine pieces of the residual (AffineResidual:
+            // 27 instructions per halving, two step lengths per trip) against the value the same pieces give at s = 0 -- the
+            // regime's own, self-consistent evaluation, as the reference's loop is: it ends where s r' drops below half an
+            // ulp of r.  The trial it ends on is the new state; its sums, in the carried form, are the next step's.
+            if (__builtin_amdgcn_ballot_w64(frozen) != 0ull) {
+                used = true;
+                if (frozen) {
+                    accel_grads_u(k, v, et, u0, u1);      // (the loop above may have been left before it came round to this trial)
+                    AffineResidual<T, VARIANT> ar;
+                    ar.setup(et, [&](int i) { return (T)bk[(3 + i) * 64]; }, dl, p, L);
+                    ar.search(kp, ar(T(0)), s, it, diag);
 #pragma unroll
-                    for (int i = 0; i < NC; ++i) lam[i] = bk[(3 + i) * 64];
-                    accel_values_u(k, v, t0, t1, et, u0, u1);
+                    for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, bk[(3 + i) * 64]);
+                    residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);
                 }
             }
-        } while (__builtin_amdgcn_ballot_w64(open) != 0ull);
+        }
+        if (used) it = 0;
     }
     c.r0 = et.r0; c.r1 = et.r1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { c.a[j] = et.a[j]; c.gt[j] = et.gt[j]; }
+}
+
+// (the gated solve's call: no bookkeeping, no frozen regime)
+template <typename T, int VARIANT, class P>
+__device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T> &kp, T gap, T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
+                                                    AccCarry<T, true, true> &c, LdsBackup<T> bk, int &it)
+{
+    NoDiag none;
+    newton_step_inplace<T, VARIANT, P, false, NoDiag>(k, kp, gap, v, t0, t1, lam, c, bk, it, none);
 }
 
 // the common call: no bookkeeping

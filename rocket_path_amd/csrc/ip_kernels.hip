@@ -135,15 +135,25 @@ template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
 // step(k) stays bit-identical to k x step(1).
 // WAVE (ungated launches only, whose live lanes all take the same k steps together): the residual loop's stragglers are served
 // by the whole wave (newton_step_to, "wave-parallel line search").
+// Which step a launch runs.  In place (newton_step_inplace: the step's start waits in LDS, residual sums carried, wave-uniform
+// loops): the gated solve in the reference's mu mode, and -- round 4 -- EVERY fixed-step launch of F3, whose kernels ran
+// newton_step_to with per-lane loop exits until then (389 VALU instructions per step against the gated kernel's 307).  Since all
+// of F3's fixed-step kernels run the one function, step(k) is k x step(1) bit for bit in every launch shape as before, and a
+// gated launch whose gate never closes now takes the very same steps as well.  F4's fixed-step launches keep newton_step_to (the
+// wave-parallel line search and the affine post-convergence loop are built on it); mu_mode 1 likewise.
+template <int VARIANT, bool GATED, int MU, class D>
+constexpr bool kStepInPlace = RP_GATED_IN_PLACE && MU == 0 && (GATED ? std::is_same<D, NoDiag>::value : VARIANT == 3);
+
 template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open, D &diag, LdsBackup<T> backup = nullptr)
 {
     static_assert(!(WAVE && GATED), "lanes of a gated solve leave the loop at different steps");
+    constexpr bool INPLACE = kStepInPlace<VARIANT, GATED, MU, D>;
     // gated kernels carry the time derivatives as well (newton_step's MEMO = !GATED) and, in the reference's mu mode, the
-    // residual sums, from which the gap of the current point comes for free
-    using Carry = AccCarry<T, GATED, GATED && MU == 0>;
+    // residual sums, from which the gap of the current point comes for free; so does every launch that steps in place
+    using Carry = AccCarry<T, GATED || INPLACE, (GATED && MU == 0) || INPLACE>;
     Carry e;            // the evaluation at the current point, carried from step to step
     auto evaluate = [&]() {
         Acc<T> e0;
@@ -151,7 +161,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
         e.r0 = e0.r0; e.r1 = e0.r1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) e.a[j] = e0.a[j];
-        if constexpr (GATED) {
+        if constexpr (GATED || INPLACE) {
             accel_grads(pr, v, e0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) e.gt[j] = e0.gt[j];
@@ -171,10 +181,32 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     [[maybe_unused]] int left = max_iter - it;      // GATED: steps this problem may still take -- the ONE per-lane counter of the solve (it = max_iter - left
                                                     // afterwards; the caller has the count it came in with and takes the difference as steps_here)
     [[maybe_unused]] int taken = 0;                 // (STALL only: whether this launch moved the problem at all)
-    if constexpr (GATED) {
+    [[maybe_unused]] int halvings = 0;              // the in-place step's line-search counter: zero whenever a loop is entered (newton_step_inplace)
+    if constexpr (GATED && !STALL) {
         // Wave-uniform loop: it runs while any lane of the wave still has steps to take, and a lane that has reached its gate
         // sits the rest out under the execution mask.  (Lanes leaving a loop one by one make the compiler copy every value that
-        // is live after it -- the whole state -- at every trip.)
+        // is live after it -- the whole state -- at every trip.)  The test is a ballot over the gate's own comparisons -- a lane
+        // that has passed its gate passes it again, its state no longer moves -- and the status bits are read off the final
+        // point afterwards: nothing is carried round the loop but the state.
+        for (int s = 0; s < k; ++s) {
+            const T gap = current_gap();
+            const bool go = !(gap < tol) && left > 0;
+            if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
+            if (go) {
+                if constexpr (INPLACE)
+                    newton_step_inplace<T, VARIANT, P>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings);      // the step's start waits in LDS, the accepted trial is the state
+                else
+                    newton_step<T, VARIANT, P, false, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);      // gated solves never reach the regime the memoisation is for
+                if constexpr (sizeof(S) != sizeof(T)) {
+                    v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
+#pragma unroll
+                    for (int c = 0; c < CMap<VARIANT>::NC; ++c) lam[c] = (T)(S)lam[c];
+                    evaluate();                      // the carried evaluation belongs to the unrounded point
+                }
+                --left;
+            }
+        }
+    } else if constexpr (GATED) {
         bool open = true;
         for (int s = 0; s < k; ++s) {
             if (open) {
@@ -186,10 +218,10 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                     else if (++since_best >= kp.stall_window) { st |= RP_ST_STALLED; done = true; open = false; }
                 }
                 if (open) {
-                    if constexpr (MU == 0 && std::is_same<D, NoDiag>::value && RP_GATED_IN_PLACE)
-                        newton_step_inplace<T, VARIANT, P>(pr, kp, gap, v, t0, t1, lam, e, backup);      // the step's start waits in LDS, the accepted trial is the state
+                    if constexpr (INPLACE)
+                        newton_step_inplace<T, VARIANT, P>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings);
                     else
-                        newton_step<T, VARIANT, P, false, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);      // gated solves never reach the regime the memoisation is for
+                        newton_step<T, VARIANT, P, false, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);
                     if constexpr (sizeof(S) != sizeof(T)) {
                         v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
 #pragma unroll
@@ -197,7 +229,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                         evaluate();                      // the carried evaluation belongs to the unrounded point
                     }
                     --left;
-                    if constexpr (STALL) ++taken;
+                    ++taken;
                 }
             }
             if (__builtin_amdgcn_ballot_w64(open) == 0ull) break;
@@ -205,7 +237,10 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     } else
     for (int s = 0; s < k; ++s) {
         const T gap = current_gap();
-        newton_step<T, VARIANT, P, true, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);
+        if constexpr (INPLACE)
+            newton_step_inplace<T, VARIANT, P, true, D>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings, diag);      // FROZEN: with the post-convergence regime's loops
+        else
+            newton_step<T, VARIANT, P, true, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);
         if constexpr (sizeof(S) != sizeof(T)) {
             v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
 #pragma unroll
@@ -217,7 +252,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     if constexpr (GATED) it = max_iter - left;
     else it += steps_here;
     if (GATED) {
-        if (!done) {   // settle the status now so the host knows whether to launch again
+        if (!done) {   // the status of the point the launch leaves (and so the host knows whether to launch again)
             const T gap = current_gap();
             if (gap < tol) { st |= RP_ST_CONVERGED; done = true; }
             else if (left <= 0) { st |= RP_ST_MAXITER; done = true; }
@@ -321,7 +356,7 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     bool still_open = false;
     // where the in-place step (newton_step_inplace) parks the point and multipliers a step started from: 11 (F4: 7) fields x 64 lanes
     // ... and the problem's two deltas (ProbLds): 13 (9) fields
-    constexpr bool kInPlace = MU == 0 && RP_GATED_IN_PLACE;
+    constexpr bool kInPlace = kStepInPlace<VARIANT, true, MU, NoDiag>;
     __shared__ T s_backup[kInPlace ? (3 + NC + 2) * 64 : 1];
 
     if (active) {
@@ -429,12 +464,18 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
 // late in round 2 this was a 512-problem tile staged in LDS, the only form that fitted three waves per SIMD: the compiler
 // kept the eleven store addresses in registers across the steps.  Forming them after the steps, below, saved 16 VGPRs and
 // made the direct form both fit and win: 57.5 -> 65.5 G steps/s at k = 12.)
+template <int VARIANT> constexpr int kStepsChunkWaves = kStepInPlace<VARIANT, false, 0, NoDiag> ? RP_GATED_WAVES : RP_TILED_WAVES;
+
 template <typename S, typename T, int VARIANT, bool ZV>
-__global__ void __launch_bounds__(64, RP_TILED_WAVES)
+__global__ void __launch_bounds__(64, kStepsChunkWaves<VARIANT>)
 k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
+    // F3 steps in place, as the gated solve does (round 4): the step's start and the problem's two deltas wait in LDS, 128 VGPRs,
+    // four waves per SIMD; F4 keeps newton_step_to with the wave-parallel line search at three
+    constexpr bool kInPlace = kStepInPlace<VARIANT, false, 0, NoDiag>;
+    __shared__ T s_backup[kInPlace ? (3 + NC + 2) * 64 : 1];
     const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     S *f = base + i;
@@ -456,9 +497,21 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     int it = 0, steps_here = 0;
     uint32_t st = 0u;
     bool still_open = false;
+    if constexpr (kInPlace) {
+        LdsBackup<T> col = (LdsBackup<T>)&s_backup[threadIdx.x];
+        col[(3 + NC) * 64] = pr.dx0;
+        col[(3 + NC + 1) * 64] = pr.dx1;
+        ProbLds<T, ZV> pl;
+        if constexpr (!ZV) { pl.v0 = pr.v0; pl.v2 = pr.v2; }
+        pl.dx0.at = col + (3 + NC) * 64;
+        pl.dx1.at = col + (3 + NC + 1) * 64;
+        NoDiag none;
+        run_lane<T, VARIANT, false, false, ProbLds<T, ZV>, S, false, 0, NoDiag, false>(pl, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, none, col);
+    } else {
     // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
-    // its stalled problems), so all its fixed-step kernels use it and agree bit for bit; F3's would spill at three waves
+    // its stalled problems), so all its fixed-step kernels use it and agree bit for bit
     run_lane<T, VARIANT, false, false, Pk, S, kAffine<VARIANT>, 0, RP_WAVE_LS && (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+    }
     // the store addresses are formed only now: the barrier keeps the compiler from holding eleven of them in registers
     // across the steps (168 VGPRs and 4-10 spilled without it, 152 with it)
     size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -488,6 +541,9 @@ k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
     constexpr int NF = CB + 5;
+    constexpr bool kInPlace = kStepInPlace<VARIANT, false, MU, NoDiag>;      // F3 in the reference's mu mode: the step's start waits in LDS
+    __shared__ T s_backup[kInPlace ? (3 + NC) * kBlock : 1];
+    [[maybe_unused]] LdsBackup<T> col = (LdsBackup<T>)&s_backup[(threadIdx.x >> 6) * (3 + NC) * 64 + (threadIdx.x & 63)];      // per wave: fields 64 apart
     const size_t step = (size_t)gridDim.x * kBlock;
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     LaneState<S, NF> cur, nxt;      // the prefetched state waits in the storage type
@@ -519,7 +575,7 @@ k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>, MU>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>, MU>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, kInPlace ? col : nullptr);
         S *f = base + i;
         f[0 * stride] = (S)v;
         f[1 * stride] = (S)t0;
@@ -542,6 +598,9 @@ k_newton_counted(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
+    constexpr bool kInPlace = kStepInPlace<VARIANT, false, 0, HalvingDiag>;
+    __shared__ T s_backup[kInPlace ? (3 + NC) * kBlock : 1];
+    [[maybe_unused]] LdsBackup<T> col = (LdsBackup<T>)&s_backup[(threadIdx.x >> 6) * (3 + NC) * 64 + (threadIdx.x & 63)];
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     S *f = base + i;
@@ -555,26 +614,12 @@ k_newton_counted(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T
     pr.v2 = (T)f[(CB + 4) * stride];
     pr.dx0 = p1 - p0;
     pr.dx1 = p2 - p1;
-    AccCarry<T, false, false> e;
-    auto evaluate = [&]() {
-        Acc<T> e0;
-        accel_values(pr, v, t0, t1, e0);
-        e.r0 = e0.r0; e.r1 = e0.r1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e.a[j] = e0.a[j];
-    };
-    evaluate();
     HalvingDiag diag;
-    for (int s = 0; s < k; ++s) {
-        const T gap = duality_gap<T, VARIANT, AccCarry<T, false, false>>(e, lam, kp.limit);
-        newton_step<T, VARIANT, Prob<T, false>, true, kAffine<VARIANT>, 0, HalvingDiag>(pr, kp, gap, v, t0, t1, lam, e, diag);
-        if constexpr (sizeof(S) != sizeof(T)) {
-            v = (T)(S)v; t0 = (T)(S)t0; t1 = (T)(S)t1;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) lam[c] = (T)(S)lam[c];
-            evaluate();
-        }
-    }
+    int it = 0, steps_here = 0;
+    uint32_t st = 0u;
+    bool still_open = false;
+    run_lane<T, VARIANT, false, false, Prob<T, false>, S, kAffine<VARIANT>, 0, HalvingDiag, false>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, diag,
+                                                                                                   kInPlace ? col : nullptr);
     f[0 * stride] = (S)v;
     f[1 * stride] = (S)t0;
     f[2 * stride] = (S)t1;
@@ -612,6 +657,9 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
     constexpr int NF = CB + 5;
     constexpr int PER = Vec16<S, T>::PER;
     using V = typename Vec16<S, T>::type;
+    constexpr bool kInPlace = kStepInPlace<VARIANT, false, 0, NoDiag>;      // F3: the step's start waits in LDS
+    __shared__ T s_backup[kInPlace ? (3 + NC) * kBlock : 1];
+    [[maybe_unused]] LdsBackup<T> col = (LdsBackup<T>)&s_backup[(threadIdx.x >> 6) * (3 + NC) * 64 + (threadIdx.x & 63)];
     const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * PER;
     V f[NF];
 #pragma unroll
@@ -644,7 +692,7 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, kInPlace ? col : nullptr);
         f[0][c] = (S)v;
         f[1][c] = (S)t0;
         f[2][c] = (S)t1;
