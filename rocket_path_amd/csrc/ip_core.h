@@ -227,21 +227,28 @@ template <> struct CMap<3> { static constexpr int NC = 8; };   // onedpath_ip.cp
 template <> struct CMap<4> { static constexpr int NC = 4; };   // onedpath2_ip.cpp
 
 // accelerations only: enough for constraintsSatisfied (onedpath_ip.cpp:738-751); u0, u1 = dX / t come back for accel_grads_u
+// (kdx0, kdx1: the problem's two deltas, passed in by callers that have read them from LDS together with other values)
 template <typename T, class P>
-__device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, T &u0, T &u1)
+__device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, T &u0, T &u1, T kdx0, T kdx1)
 {
     const T rr = rcp_(t0 * t1);                               // one reciprocal for both durations: 1/t0 = t1/(t0 t1)
     const T r0 = t1 * rr, r1 = t0 * rr;
     e.r0 = r0;
     e.r1 = r1;
-    u0 = k.dx0 * r0;                                          // dX / t
-    u1 = k.dx1 * r1;
+    u0 = kdx0 * r0;                                           // dX / t
+    u1 = kdx1 * r1;
     const T m0 = seg0_m<T>(k, v), n0 = seg0_n<T>(k, v);       // segment 0: v1 = vel1
     const T m1 = seg1_m<T>(k, v), n1 = seg1_n<T>(k, v);       // segment 1: v0 = vel1
     e.a[0] = fma_(T(6), u0, m0) * r0;
     e.a[1] = fma_(T(-6), u0, n0) * r0;
     e.a[2] = fma_(T(6), u1, m1) * r1;
     e.a[3] = fma_(T(-6), u1, n1) * r1;
+}
+template <typename T, class P>
+__device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, T &u0, T &u1)
+{
+    const T kdx0 = k.dx0, kdx1 = k.dx1;      // (read first: from LDS in the in-place kernels, under the reciprocal)
+    accel_values_u(k, v, t0, t1, e, u0, u1, kdx0, kdx1);
 }
 template <typename T, class P>
 __device__ __forceinline__ void accel_values(const P &k, T v, T t0, T t1, Acc<T> &e)
@@ -949,6 +956,8 @@ template <typename T, int VARIANT> struct AffineResidual {
             for (int q = 1; q < W; ++q) sk[q] = sk[q - 1] * kp.backtrack;
 #pragma unroll
             for (int q = 0; q < W; ++q) rn[q] = (*this)(sk[q]);
+#pragma unroll
+            for (int q = 0; q < W; ++q) asm volatile("" : "+v"(rn[q]));      // (opaque: or the compiler sinks the later evaluations behind the test of the first and serialises them)
             const int valid = (kp.max_bt - it < W) ? kp.max_bt - it : W;      // trials the reference would still make
             int first = W;                                                    // first accepted trial of this trip
 #pragma unroll
@@ -1547,13 +1556,14 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 diag.resid();
                 // (all eleven reads are issued before the first use: the multipliers arrive under the trial point's evaluation)
                 const T x0 = bk[0 * 64], x1 = bk[1 * 64], x2 = bk[2 * 64];
+                const T kdx0 = k.dx0, kdx1 = k.dx1;
 #pragma unroll
                 for (int i = 0; i < NC; ++i) lam[i] = bk[(3 + i) * 64];
                 v = fma_(dxv, s, x0);
                 t0 = fma_(dx0, s, x1);
                 t1 = fma_(dx1, s, x2);
                 if constexpr (FROZEN) frozen = v == x0 && t0 == x1 && t1 == x2;
-                accel_values_u(k, v, t0, t1, et, u0, u1);
+                accel_values_u(k, v, t0, t1, et, u0, u1, kdx0, kdx1);
 #pragma unroll
                 for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
             }
