@@ -1450,11 +1450,24 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 // has a rejected feasibility trial, a rejected residual trial is rare before convergence), and the loops run while ANY lane of
 // the wave is inside (wave-uniform exits: nothing to copy).  Same functions, same operands, same order of decisions as
 // newton_step_to<MEMO = false, MU = 0>: every bit of every iterate is the same (tests/checks/inplace_ab.py, 36 cases).
-// bk: this lane's column of the block's backup area, field q at bk[q * 64]; volatile so that the compiler neither forwards the
+// bk: where the step's start waits (LdsColumn: this lane's column of the block's backup area, field q at p[q * 64]; volatile so that the compiler neither forwards the
 // stored values to the reads (keeping them in registers is what this form is there to avoid) nor drops the stores.
 // The loops are written with the trial formed where s is set (at the bottom, from the backed-up start), so that a trial
 // is a multiply-add INTO the state registers.
 template <typename T> using LdsBackup = __attribute__((address_space(3))) volatile T *;      // LDS address space kept in the type: ds_read / ds_write, not flat accesses
+// Where the step's start waits: this lane's column of the block's LDS area (field q at p[q * 64]) -- the form the large-batch
+// kernels are built around, four waves per SIMD -- or, for batches too small to fill the chip (a lone wave per SIMD has nothing
+// to run under an LDS round trip: BASELINE configs[1]), plain registers at three.
+template <typename T> struct LdsColumn {
+    LdsBackup<T> p;
+    __device__ __forceinline__ T get(int q) const { return p[q * 64]; }
+    __device__ __forceinline__ void put(int q, T x) const { p[q * 64] = x; }
+};
+template <typename T, int N> struct RegColumn {
+    T r[N];
+    __device__ __forceinline__ T get(int q) const { return r[q]; }
+    __device__ __forceinline__ void put(int q, T x) { r[q] = x; }
+};
 
 // FROZEN (the fixed-step kernels: a gated solve stops long before): the reference's post-convergence regime, where x no longer
 // moves and every step still walks ~48 residual halvings (onedpath_ip.cpp:932-945), gets its own search -- see "frozen" below.
@@ -1465,9 +1478,9 @@ template <typename T> using LdsBackup = __attribute__((address_space(3))) volati
 // mask; a lane whose trial has passed simply re-evaluates its unchanged trial (same values, the instructions issue for the wave
 // anyway) while others retry.  The halving counter `it` is touched only where a trial fails: it enters every loop as zero and is
 // put back to zero behind a wave-uniform branch when some lane used it.
-template <typename T, int VARIANT, class P, bool FROZEN = false, class D = NoDiag>
+template <typename T, int VARIANT, class P, bool FROZEN = false, class D = NoDiag, class BK = LdsColumn<T>>
 __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T> &kp, T gap, T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
-                                                    AccCarry<T, true, true> &c, LdsBackup<T> bk, int &it, D &diag)
+                                                    AccCarry<T, true, true> &c, BK &bk, int &it, D &diag)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     const T L = kp.limit;
@@ -1484,9 +1497,9 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
         else direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect);
     }
     const T r0n = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);      // onedpath_ip.cpp:932
-    bk[0 * 64] = v; bk[1 * 64] = t0; bk[2 * 64] = t1;
+    bk.put(0, v); bk.put(1, t0); bk.put(2, t1);
 #pragma unroll
-    for (int i = 0; i < NC; ++i) bk[(3 + i) * 64] = lam[i];
+    for (int i = 0; i < NC; ++i) bk.put(3 + i, lam[i]);
 
     T s = boundary_fraction<T, NC>(kp, lam, dl, sg, suspect);         // onedpath_ip.cpp:903-915
 
@@ -1523,7 +1536,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                     s *= kp.backtrack;
                     ++it;
                     diag.feas();
-                    const T x0 = bk[0 * 64], x1 = bk[1 * 64], x2 = bk[2 * 64];
+                    const T x0 = bk.get(0), x1 = bk.get(1), x2 = bk.get(2);
                     v = fma_(dxv, s, x0);
                     t0 = fma_(dx0, s, x1);
                     t1 = fma_(dx1, s, x2);
@@ -1555,10 +1568,10 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 ++it;
                 diag.resid();
                 // (all eleven reads are issued before the first use: the multipliers arrive under the trial point's evaluation)
-                const T x0 = bk[0 * 64], x1 = bk[1 * 64], x2 = bk[2 * 64];
+                const T x0 = bk.get(0), x1 = bk.get(1), x2 = bk.get(2);
                 const T kdx0 = k.dx0, kdx1 = k.dx1;
 #pragma unroll
-                for (int i = 0; i < NC; ++i) lam[i] = bk[(3 + i) * 64];
+                for (int i = 0; i < NC; ++i) lam[i] = bk.get(3 + i);
                 v = fma_(dxv, s, x0);
                 t0 = fma_(dx0, s, x1);
                 t1 = fma_(dx1, s, x2);
@@ -1585,10 +1598,10 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 if (frozen) {
                     accel_grads_u(k, v, et, u0, u1);      // (the loop above may have been left before it came round to this trial)
                     AffineResidual<T, VARIANT> ar;
-                    ar.setup(et, [&](int i) { return (T)bk[(3 + i) * 64]; }, dl, p, L);
+                    ar.setup(et, [&](int i) { return (T)bk.get(3 + i); }, dl, p, L);
                     ar.search(kp, ar(T(0)), s, it, diag);
 #pragma unroll
-                    for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, bk[(3 + i) * 64]);
+                    for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, bk.get(3 + i));
                     residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);
                 }
             }
@@ -1601,12 +1614,12 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
 }
 
 // (the gated solve's call: no bookkeeping, no frozen regime)
-template <typename T, int VARIANT, class P>
+template <typename T, int VARIANT, class P, class BK>
 __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T> &kp, T gap, T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
-                                                    AccCarry<T, true, true> &c, LdsBackup<T> bk, int &it)
+                                                    AccCarry<T, true, true> &c, BK &bk, int &it)
 {
     NoDiag none;
-    newton_step_inplace<T, VARIANT, P, false, NoDiag>(k, kp, gap, v, t0, t1, lam, c, bk, it, none);
+    newton_step_inplace<T, VARIANT, P, false, NoDiag, BK>(k, kp, gap, v, t0, t1, lam, c, bk, it, none);
 }
 
 // the common call: no bookkeeping

@@ -144,10 +144,11 @@ template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
 template <int VARIANT, bool GATED, int MU, class D>
 constexpr bool kStepInPlace = RP_GATED_IN_PLACE && MU == 0 && (GATED ? std::is_same<D, NoDiag>::value : VARIANT == 3);
 
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false>
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false,
+          class BK = LdsColumn<T>>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
-                                         int &it, uint32_t &st, int &steps_here, bool &still_open, D &diag, LdsBackup<T> backup = nullptr)
+                                         int &it, uint32_t &st, int &steps_here, bool &still_open, D &diag, BK backup = BK{})
 {
     static_assert(!(WAVE && GATED), "lanes of a gated solve leave the loop at different steps");
     constexpr bool INPLACE = kStepInPlace<VARIANT, GATED, MU, D>;
@@ -194,7 +195,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
             if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
             if (go) {
                 if constexpr (INPLACE)
-                    newton_step_inplace<T, VARIANT, P>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings);      // the step's start waits in LDS, the accepted trial is the state
+                    newton_step_inplace<T, VARIANT, P, BK>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings);      // the step's start waits in LDS, the accepted trial is the state
                 else
                     newton_step<T, VARIANT, P, false, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);      // gated solves never reach the regime the memoisation is for
                 if constexpr (sizeof(S) != sizeof(T)) {
@@ -219,7 +220,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                 }
                 if (open) {
                     if constexpr (INPLACE)
-                        newton_step_inplace<T, VARIANT, P>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings);
+                        newton_step_inplace<T, VARIANT, P, BK>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings);
                     else
                         newton_step<T, VARIANT, P, false, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);
                     if constexpr (sizeof(S) != sizeof(T)) {
@@ -238,7 +239,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     for (int s = 0; s < k; ++s) {
         const T gap = current_gap();
         if constexpr (INPLACE)
-            newton_step_inplace<T, VARIANT, P, true, D>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings, diag);      // FROZEN: with the post-convergence regime's loops
+            newton_step_inplace<T, VARIANT, P, true, D, BK>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings, diag);      // FROZEN: with the post-convergence regime's loops
         else
             newton_step<T, VARIANT, P, true, AFFINE, MU, D, WAVE>(pr, kp, gap, v, t0, t1, lam, e, diag);
         if constexpr (sizeof(S) != sizeof(T)) {
@@ -282,7 +283,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
 template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, bool WAVE = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
-                                         int &it, uint32_t &st, int &steps_here, bool &still_open, LdsBackup<T> backup = nullptr)
+                                         int &it, uint32_t &st, int &steps_here, bool &still_open, LdsColumn<T> backup = LdsColumn<T>{})
 {
     NoDiag none;
     run_lane<T, VARIANT, GATED, STALL, P, S, AFFINE, MU, NoDiag, WAVE>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open, none, backup);
@@ -405,7 +406,7 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
             pl.dx0.at = col + (3 + NC) * 64;
             pl.dx1.at = col + (3 + NC + 1) * 64;
             NoDiag none;
-            run_lane<T, VARIANT, true, STALL, ProbLds<T, ZV>, S, false, MU, NoDiag, false>(pl, kp, k, tol, max_iter, v, t0, t1, lam, it_new, flags, steps_here, still_open, none, col);
+            run_lane<T, VARIANT, true, STALL, ProbLds<T, ZV>, S, false, MU, NoDiag, false>(pl, kp, k, tol, max_iter, v, t0, t1, lam, it_new, flags, steps_here, still_open, none, LdsColumn<T>{col});
         } else {
             run_lane<T, VARIANT, true, STALL, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it_new, flags, steps_here, still_open);
         }
@@ -464,10 +465,14 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
 // late in round 2 this was a 512-problem tile staged in LDS, the only form that fitted three waves per SIMD: the compiler
 // kept the eleven store addresses in registers across the steps.  Forming them after the steps, below, saved 16 VGPRs and
 // made the direct form both fit and win: 57.5 -> 65.5 G steps/s at k = 12.)
-template <int VARIANT> constexpr int kStepsChunkWaves = kStepInPlace<VARIANT, false, 0, NoDiag> ? RP_GATED_WAVES : RP_TILED_WAVES;
+template <int VARIANT, bool REGBK> constexpr int kStepsChunkWaves = (kStepInPlace<VARIANT, false, 0, NoDiag> && !REGBK) ? RP_GATED_WAVES : RP_TILED_WAVES;
 
-template <typename S, typename T, int VARIANT, bool ZV>
-__global__ void __launch_bounds__(64, kStepsChunkWaves<VARIANT>)
+// REGBK (F3): the in-place step's start waits in registers instead of LDS, three waves per SIMD -- the instantiation for batches
+// that cannot fill three waves per SIMD anyway (launch_steps picks it below 196,608 problems): a lone wave has nothing to run
+// under an LDS round trip, and the post-convergence regime of a fixed-step run (BASELINE configs[1], 65,536 problems x 50 steps)
+// makes one per halving.  Same arithmetic, same bits.
+template <typename S, typename T, int VARIANT, bool ZV, bool REGBK = false>
+__global__ void __launch_bounds__(64, (kStepsChunkWaves<VARIANT, REGBK>))
 k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
 {
     constexpr int NC = CMap<VARIANT>::NC;
@@ -475,7 +480,8 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     // F3 steps in place, as the gated solve does (round 4): the step's start and the problem's two deltas wait in LDS, 128 VGPRs,
     // four waves per SIMD; F4 keeps newton_step_to with the wave-parallel line search at three
     constexpr bool kInPlace = kStepInPlace<VARIANT, false, 0, NoDiag>;
-    __shared__ T s_backup[kInPlace ? (3 + NC + 2) * 64 : 1];
+    static_assert(kInPlace || !REGBK, "the register column belongs to the in-place step");
+    __shared__ T s_backup[(kInPlace && !REGBK) ? (3 + NC + 2) * 64 : 1];
     const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     S *f = base + i;
@@ -497,7 +503,14 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     int it = 0, steps_here = 0;
     uint32_t st = 0u;
     bool still_open = false;
-    if constexpr (kInPlace) {
+    if constexpr (kInPlace && REGBK) {
+        NoDiag none;
+        Prob<T, ZV> pq;
+        if constexpr (!ZV) { pq.v0 = pr.v0; pq.v2 = pr.v2; }
+        pq.dx0 = pr.dx0;
+        pq.dx1 = pr.dx1;
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, false, 0, NoDiag, false, RegColumn<T, 3 + NC>>(pq, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, none);
+    } else if constexpr (kInPlace) {
         LdsBackup<T> col = (LdsBackup<T>)&s_backup[threadIdx.x];
         col[(3 + NC) * 64] = pr.dx0;
         col[(3 + NC + 1) * 64] = pr.dx1;
@@ -506,7 +519,7 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
         pl.dx0.at = col + (3 + NC) * 64;
         pl.dx1.at = col + (3 + NC + 1) * 64;
         NoDiag none;
-        run_lane<T, VARIANT, false, false, ProbLds<T, ZV>, S, false, 0, NoDiag, false>(pl, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, none, col);
+        run_lane<T, VARIANT, false, false, ProbLds<T, ZV>, S, false, 0, NoDiag, false>(pl, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, none, LdsColumn<T>{col});
     } else {
     // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
     // its stalled problems), so all its fixed-step kernels use it and agree bit for bit
@@ -575,7 +588,7 @@ k_newton_stream(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T>
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>, MU>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, kInPlace ? col : nullptr);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>, MU>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, LdsColumn<T>{col});
         S *f = base + i;
         f[0 * stride] = (S)v;
         f[1 * stride] = (S)t0;
@@ -619,7 +632,7 @@ k_newton_counted(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T
     uint32_t st = 0u;
     bool still_open = false;
     run_lane<T, VARIANT, false, false, Prob<T, false>, S, kAffine<VARIANT>, 0, HalvingDiag, false>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, diag,
-                                                                                                   kInPlace ? col : nullptr);
+                                                                                                   LdsColumn<T>{col});
     f[0 * stride] = (S)v;
     f[1 * stride] = (S)t0;
     f[2 * stride] = (S)t1;
@@ -692,7 +705,7 @@ k_newton_stream16(S *__restrict__ base, size_t stride, int k, KParams<T> kp)
         int it = 0, steps_here = 0;
         uint32_t st = 0;
         bool still_open = false;
-        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, kInPlace ? col : nullptr);
+        run_lane<T, VARIANT, false, false, Prob<T, ZV>, S, kAffine<VARIANT>>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open, LdsColumn<T>{col});
         f[0][c] = (S)v;
         f[1][c] = (S)t0;
         f[2][c] = (S)t1;
@@ -1171,6 +1184,14 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
         else                     { using S [[maybe_unused]] = float;  using T [[maybe_unused]] = double; RP_DISPATCH_V(b, __VA_ARGS__); } \
     } while (0)
 
+// dispatch on the dtype alone (S, T)
+#define RP_DISPATCH_ST(b, ...)                                                                           \
+    do {                                                                                                 \
+        if ((b).dtype == 0)      { using S [[maybe_unused]] = double; using T [[maybe_unused]] = double; __VA_ARGS__; } \
+        else if ((b).dtype == 1) { using S [[maybe_unused]] = float;  using T [[maybe_unused]] = float;  __VA_ARGS__; } \
+        else                     { using S [[maybe_unused]] = float;  using T [[maybe_unused]] = double; __VA_ARGS__; } \
+    } while (0)
+
 }  // namespace
 
 // the three Newton kernels are also instantiated for "end velocities are zero" (BatchView::zero_end_vel)
@@ -1220,6 +1241,13 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
     constexpr bool scalar_only = false;
 #endif
     if (k >= chunks_from && k >= 1 && !grid_env) {
+        // F3 below three waves per SIMD (3 x 1,024 SIMDs x 64 lanes): the instantiation whose step keeps its start in registers
+        if (b.variant == 3 && b.n <= (size_t)3 * 1024 * 64) {
+            constexpr int V3 = 3;
+            if (b.zero_end_vel) { constexpr bool Z = true;  RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3))); }
+            else                { constexpr bool Z = false; RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3))); }
+            return hipGetLastError();
+        }
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V, Z>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
                                              (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
         return hipGetLastError();
