@@ -200,6 +200,14 @@ template <typename T> struct Acc {
     T a[4];
     T gt[4];       // d a_j / d t_seg(j)   (not carried from step to step: rebuilt by accel_grads, see newton_step)
 };
+// What the evaluation of a point leaves behind for the stages that follow it (the time derivatives, the next direction's second
+// derivatives): u = dX / t of both segments and the four velocity combinations -- exact re-uses, the same products wherever they
+// are formed.  (With zero end velocities the combinations are +-2v and +-4v: two registers.)
+template <typename T> struct PointAux {
+    T u0, u1;
+    T m0, n0, m1, n1;
+};
+
 // What a lane carries from one step to the next: the reciprocals and the four accelerations.
 // GT = false: the time derivatives are rebuilt at the start of the step (14 flop) -- eight registers that are then free in
 // the residual backtracking loop, the register peak of the fixed-step kernels (memoisation state on top).  GT = true
@@ -213,6 +221,7 @@ template <typename T, bool GT = false, bool RS = false> struct AccCarry {
     T gt[GT ? 4 : 1];
     T X, Q1, Q2;      // unused (and not live) unless RS
     T cm[RS ? 4 : 1], cp[RS ? 4 : 1];      // with RS, F3: the constraint values -a_j - L, a_j - L the sums were formed from -- the next direction starts from them
+    PointAux<T> x;                         // with RS: dX / t and the velocity combinations of the point (the direction's second derivatives re-use them)
 };
 
 // d a_j / d vel1: dAdV1 of segment 0's ends (-2/t0, 4/t0), dAdV0 of segment 1's ends (-4/t1, 2/t1)
@@ -226,54 +235,56 @@ template <int VARIANT> struct CMap;
 template <> struct CMap<3> { static constexpr int NC = 8; };   // onedpath_ip.cpp:101
 template <> struct CMap<4> { static constexpr int NC = 4; };   // onedpath2_ip.cpp
 
-// accelerations only: enough for constraintsSatisfied (onedpath_ip.cpp:738-751); u0, u1 = dX / t come back for accel_grads_u
+// accelerations only: enough for constraintsSatisfied (onedpath_ip.cpp:738-751)
 // (kdx0, kdx1: the problem's two deltas, passed in by callers that have read them from LDS together with other values)
 template <typename T, class P>
-__device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, T &u0, T &u1, T kdx0, T kdx1)
+__device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, PointAux<T> &x, T kdx0, T kdx1)
 {
     const T rr = rcp_(t0 * t1);                               // one reciprocal for both durations: 1/t0 = t1/(t0 t1)
     const T r0 = t1 * rr, r1 = t0 * rr;
     e.r0 = r0;
     e.r1 = r1;
-    u0 = kdx0 * r0;                                           // dX / t
-    u1 = kdx1 * r1;
-    const T m0 = seg0_m<T>(k, v), n0 = seg0_n<T>(k, v);       // segment 0: v1 = vel1
-    const T m1 = seg1_m<T>(k, v), n1 = seg1_n<T>(k, v);       // segment 1: v0 = vel1
-    e.a[0] = fma_(T(6), u0, m0) * r0;
-    e.a[1] = fma_(T(-6), u0, n0) * r0;
-    e.a[2] = fma_(T(6), u1, m1) * r1;
-    e.a[3] = fma_(T(-6), u1, n1) * r1;
+    x.u0 = kdx0 * r0;                                         // dX / t
+    x.u1 = kdx1 * r1;
+    x.m0 = seg0_m<T>(k, v); x.n0 = seg0_n<T>(k, v);           // segment 0: v1 = vel1
+    x.m1 = seg1_m<T>(k, v); x.n1 = seg1_n<T>(k, v);           // segment 1: v0 = vel1
+    e.a[0] = fma_(T(6), x.u0, x.m0) * r0;
+    e.a[1] = fma_(T(-6), x.u0, x.n0) * r0;
+    e.a[2] = fma_(T(6), x.u1, x.m1) * r1;
+    e.a[3] = fma_(T(-6), x.u1, x.n1) * r1;
 }
 template <typename T, class P>
-__device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, T &u0, T &u1)
+__device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, PointAux<T> &x)
 {
     const T kdx0 = k.dx0, kdx1 = k.dx1;      // (read first: from LDS in the in-place kernels, under the reciprocal)
-    accel_values_u(k, v, t0, t1, e, u0, u1, kdx0, kdx1);
+    accel_values_u(k, v, t0, t1, e, x, kdx0, kdx1);
 }
 template <typename T, class P>
 __device__ __forceinline__ void accel_values(const P &k, T v, T t0, T t1, Acc<T> &e)
 {
-    T u0, u1;
-    accel_values_u(k, v, t0, t1, e, u0, u1);
+    PointAux<T> x;
+    accel_values_u(k, v, t0, t1, e, x);
 }
 
-// first derivatives, from the reciprocals already in e (dAdT, dAdV0/dAdV1 of :389-391, :430-432) and u = dX / t of the same point
-template <typename T, class P>
-__device__ __forceinline__ void accel_grads_u(const P &k, T v, Acc<T> &e, T u0, T u1)
+// first derivatives, from the reciprocals already in e (dAdT, dAdV0/dAdV1 of :389-391, :430-432) and what the values left behind
+template <typename T>
+__device__ __forceinline__ void accel_grads_u(Acc<T> &e, const PointAux<T> &x)
 {
     const T r0 = e.r0, r1 = e.r1;
-    const T m0 = seg0_m<T>(k, v), n0 = seg0_n<T>(k, v);
-    const T m1 = seg1_m<T>(k, v), n1 = seg1_n<T>(k, v);
     const T q0 = r0 * r0, q1 = r1 * r1;
-    e.gt[0] = fma_(T(-12), u0, -m0) * q0;
-    e.gt[1] = fma_(T(12), u0, -n0) * q0;
-    e.gt[2] = fma_(T(-12), u1, -m1) * q1;
-    e.gt[3] = fma_(T(12), u1, -n1) * q1;
+    e.gt[0] = fma_(T(-12), x.u0, -x.m0) * q0;
+    e.gt[1] = fma_(T(12), x.u0, -x.n0) * q0;
+    e.gt[2] = fma_(T(-12), x.u1, -x.m1) * q1;
+    e.gt[3] = fma_(T(12), x.u1, -x.n1) * q1;
 }
 template <typename T, class P>
 __device__ __forceinline__ void accel_grads(const P &k, T v, Acc<T> &e)
 {
-    accel_grads_u(k, v, e, k.dx0 * e.r0, k.dx1 * e.r1);
+    PointAux<T> x;
+    x.u0 = k.dx0 * e.r0; x.u1 = k.dx1 * e.r1;
+    x.m0 = seg0_m<T>(k, v); x.n0 = seg0_n<T>(k, v);
+    x.m1 = seg1_m<T>(k, v); x.n1 = seg1_n<T>(k, v);
+    accel_grads_u(e, x);
 }
 
 // second derivatives (evalAccelSecondDerivInit / Final, onedpath_ip.cpp:394-411, 435-452)
@@ -628,7 +639,9 @@ __device__ __forceinline__ void solve_arrow(T a, T b, T c, T d, T e, T rv, T r0,
         x0 = fma_(-b, xv, r0) * id;
         x1 = fma_(-c, xv, r1) * ie;
     } else {
-        solve3<T>(a, b, c, b, d, T(0), c, T(0), e, rv, r0, r1, xv, x0, x1);
+        T cc = c;
+        asm volatile("" : "+v"(cc));      // (opaque: or the compiler forms |c| for this rare branch's selects in front of the test, on everybody's path)
+        solve3<T>(a, b, cc, b, d, T(0), cc, T(0), e, rv, r0, r1, xv, x0, x1);
     }
 }
 
@@ -645,7 +658,7 @@ template <typename T, int VARIANT, class P, bool HAVE_C = false>
 __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v, const T (&lam)[CMap<VARIANT>::NC],
                                           const Acc<T> &e, T p, T &dxv, T &dx0, T &dx1, T (&dl)[CMap<VARIANT>::NC],
                                           T (&sg)[CMap<VARIANT>::NC], unsigned &suspect,
-                                          const T *cm_in = nullptr, const T *cp_in = nullptr)
+                                          const T *cm_in = nullptr, const T *cp_in = nullptr, const PointAux<T> *aux = nullptr)
 {
     const T L = kp.limit;
     [[maybe_unused]] T htt[4], htv[4];
@@ -702,10 +715,17 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
         {
             // S dlt_j d2a_j/dt2 with the common 1/t^3 taken out of each segment's pair (evalAccelSecondDerivInit / Final,
             // onedpath_ip.cpp:404-410, 445-451: (36 dX/t - 8 v0 - 4 v1) / t^3 and (-36 dX/t + 4 v0 + 8 v1) / t^3)
-            const T u0 = k.dx0 * r0, u1 = k.dx1 * r1;
+            T u0, u1;
             T m0d, n0d, m1d, n1d;      // 2 m0, 2 n0, 2 m1, 2 n1 of accel_values
-            if constexpr (P::zero_vel) { m0d = T(-4) * v; n0d = T(8) * v; m1d = -n0d; n1d = -m0d; }
-            else { m0d = T(2) * seg0_m<T>(k, v); n0d = T(2) * seg0_n<T>(k, v); m1d = T(2) * seg1_m<T>(k, v); n1d = T(2) * seg1_n<T>(k, v); }
+            if constexpr (HAVE_C) {      // ... which the carried evaluation of this very point has left behind (same products: same bits)
+                u0 = aux->u0; u1 = aux->u1;
+                if constexpr (P::zero_vel) { m0d = aux->m1; n0d = aux->n0 + aux->n0; m1d = -n0d; n1d = aux->n0; }      // -4v, 8v, -8v, 4v
+                else { m0d = T(2) * seg0_m<T>(k, v); n0d = T(2) * seg0_n<T>(k, v); m1d = T(2) * seg1_m<T>(k, v); n1d = T(2) * seg1_n<T>(k, v); }      // (four more values to carry: no registers)
+            } else {
+                u0 = k.dx0 * r0; u1 = k.dx1 * r1;
+                if constexpr (P::zero_vel) { m0d = T(-4) * v; n0d = T(8) * v; m1d = -n0d; n1d = -m0d; }
+                else { m0d = T(2) * seg0_m<T>(k, v); n0d = T(2) * seg0_n<T>(k, v); m1d = T(2) * seg1_m<T>(k, v); n1d = T(2) * seg1_n<T>(k, v); }
+            }
             // (36 is no inline constant: as a literal the multiply-add has to be the two-address form, which overwrites its
             // addend, and each addend is needed twice -- from a scalar register it is the three-address form, no copies)
             T c36 = T(36);
@@ -1101,7 +1121,7 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
         }
         if constexpr (MU == 0) {
 #ifndef RP_NO_CARRIED_C      // tuning knob of newton_step_to (A/B builds with RP_GATED_IN_PLACE=0): 18 more VGPRs for 8 fewer instructions per step
-            if constexpr (SUMS && VARIANT == 3) direction<T, VARIANT, P, true>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect, c.cm, c.cp);
+            if constexpr (SUMS && VARIANT == 3) direction<T, VARIANT, P, true>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect, c.cm, c.cp, &c.x);
 #else
             if constexpr (false) {}
 #endif
@@ -1493,7 +1513,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
         e.r0 = c.r0; e.r1 = c.r1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { e.a[j] = c.a[j]; e.gt[j] = c.gt[j]; }
-        if constexpr (VARIANT == 3) direction<T, VARIANT, P, true>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect, c.cm, c.cp);
+        if constexpr (VARIANT == 3) direction<T, VARIANT, P, true>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect, c.cm, c.cp, &c.x);
         else direction<T, VARIANT, P>(k, kp, v, lam, e, p, dxv, dx0, dx1, dl, sg, suspect);
     }
     const T r0n = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);      // onedpath_ip.cpp:932
@@ -1505,7 +1525,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
 
     // -- backtrack until primal feasible (onedpath_ip.cpp:919-928); a trial is formed where s is set --
     Acc<T> et;
-    T u0, u1;      // dX / t of the trial point et belongs to
+    PointAux<T> xt;      // dX / t and the velocity combinations of the trial point et belongs to
     if constexpr (VARIANT == 4) it = skip_certain_halvings<T, VARIANT, P, D>(k, kp, L, v, t0, t1, dxv, dx0, dx1, s, diag);      // (F4: its certain halvings)
     v = fma_(dxv, s, v);
     t0 = fma_(dx0, s, t0);
@@ -1514,14 +1534,15 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
         bool used = VARIANT == 4;      // wave-uniform: some lane has moved its counter
         [[maybe_unused]] bool at_x = false;      // FROZEN: the trial point has become x itself (and every later one will be)
         for (;;) {
-            accel_values_u(k, v, t0, t1, et, u0, u1);
+            accel_values_u(k, v, t0, t1, et, xt);
             const bool bad = !all_satisfied<T, VARIANT>(et, L);
-            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+            const unsigned long long any_bad = __builtin_amdgcn_ballot_w64(bad);
+            if (any_bad == 0ull) break;
             // (out of halvings: the reference goes on with an s it has not tested)
-            const bool again = bad && it < kp.max_bt;
-            if (__builtin_amdgcn_ballot_w64(again) == 0ull) break;
+            const bool room = it < kp.max_bt;
+            if ((any_bad & __builtin_amdgcn_ballot_w64(room)) == 0ull) break;
             used = true;
-            if (again) {
+            if (bad && room) {
                 if (FROZEN && at_x) {
                     // x itself fails the test by a rounding (the residual loop accepts points the feasibility loop never saw, as the
                     // reference's does) and every smaller s gives x again: the reference walks its remaining halvings to the same
@@ -1544,7 +1565,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 }
             }
         }
-        if (used) it = 0;
+        if (used) { asm volatile(""); it = 0; }      // (a branch, not a select: the common path does not touch the counter)
     }
     // -- backtrack until the residual decreases (onedpath_ip.cpp:932-945), and take the step (:949-952): the trial that ends
     // the loop -- accepted, or the last s, which the reference takes untested -- is the new state, its sums the next step's --
@@ -1554,14 +1575,17 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
         bool used = false;
         [[maybe_unused]] bool frozen = false;      // FROZEN: the trial point has become bitwise x (and stays so: s only shrinks)
         for (;;) {
-            accel_grads_u(k, v, et, u0, u1);
+            accel_grads_u(et, xt);
             residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);      // (r0n and the direction have taken what they needed from c)
             const T rn = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
             diag.moving();
             const bool bad = !(rn <= r0n * (T(1) - kp.armijo * s));
-            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
-            const bool again = bad && it < kp.max_bt && !(FROZEN && frozen);
-            if (__builtin_amdgcn_ballot_w64(again) == 0ull) break;
+            const unsigned long long any_bad = __builtin_amdgcn_ballot_w64(bad);
+            if (any_bad == 0ull) break;
+            const bool room = it < kp.max_bt;
+            const bool again = bad && room && !(FROZEN && frozen);
+            if constexpr (FROZEN) { if (__builtin_amdgcn_ballot_w64(again) == 0ull) break; }
+            else { if ((any_bad & __builtin_amdgcn_ballot_w64(room)) == 0ull) break; }
             used = true;
             if (again) {
                 s *= kp.backtrack;
@@ -1576,7 +1600,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 t0 = fma_(dx0, s, x1);
                 t1 = fma_(dx1, s, x2);
                 if constexpr (FROZEN) frozen = v == x0 && t0 == x1 && t1 == x2;
-                accel_values_u(k, v, t0, t1, et, u0, u1, kdx0, kdx1);
+                accel_values_u(k, v, t0, t1, et, xt, kdx0, kdx1);
 #pragma unroll
                 for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
             }
@@ -1596,7 +1620,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
             if (__builtin_amdgcn_ballot_w64(frozen) != 0ull) {
                 used = true;
                 if (frozen) {
-                    accel_grads_u(k, v, et, u0, u1);      // (the loop above may have been left before it came round to this trial)
+                    accel_grads_u(et, xt);      // (the loop above may have been left before it came round to this trial)
                     AffineResidual<T, VARIANT> ar;
                     ar.setup(et, [&](int i) { return (T)bk.get(3 + i); }, dl, p, L);
                     ar.search(kp, ar(T(0)), s, it, diag);
@@ -1606,9 +1630,10 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 }
             }
         }
-        if (used) it = 0;
+        if (used) { asm volatile(""); it = 0; }
     }
     c.r0 = et.r0; c.r1 = et.r1;
+    c.x = xt;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { c.a[j] = et.a[j]; c.gt[j] = et.gt[j]; }
 }

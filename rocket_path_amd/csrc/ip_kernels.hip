@@ -158,15 +158,19 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
     Carry e;            // the evaluation at the current point, carried from step to step
     auto evaluate = [&]() {
         Acc<T> e0;
-        accel_values(pr, v, t0, t1, e0);
+        PointAux<T> x0;
+        accel_values_u(pr, v, t0, t1, e0, x0);
         e.r0 = e0.r0; e.r1 = e0.r1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) e.a[j] = e0.a[j];
         if constexpr (GATED || INPLACE) {
-            accel_grads(pr, v, e0);
+            accel_grads_u(e0, x0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) e.gt[j] = e0.gt[j];
-            if constexpr (Carry::has_sums) residual_sums<T, VARIANT, false>(e0, lam, lam, T(0), kp.limit, e.X, e.Q1, e.Q2, e.cm, e.cp);
+            if constexpr (Carry::has_sums) {
+                residual_sums<T, VARIANT, false>(e0, lam, lam, T(0), kp.limit, e.X, e.Q1, e.Q2, e.cm, e.cp);
+                e.x = x0;
+            }
         }
     };
     auto current_gap = [&]() -> T {
@@ -191,9 +195,9 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
         // point afterwards: nothing is carried round the loop but the state.
         for (int s = 0; s < k; ++s) {
             const T gap = current_gap();
-            const bool go = !(gap < tol) && left > 0;
-            if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
-            if (go) {
+            const bool above = !(gap < tol), may = left > 0;
+            if ((__builtin_amdgcn_ballot_w64(above) & __builtin_amdgcn_ballot_w64(may)) == 0ull) break;      // (two ballots, each its comparison's own lane mask)
+            if (above && may) {
                 if constexpr (INPLACE)
                     newton_step_inplace<T, VARIANT, P, BK>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings);      // the step's start waits in LDS, the accepted trial is the state
                 else
