@@ -205,8 +205,17 @@ template <typename T> struct Acc {
 // are formed.  (With zero end velocities the combinations are +-2v and +-4v: two registers.)
 template <typename T> struct PointAux {
     T u0, u1;
-    T m0, n0, m1, n1;
+    T m0, n0, m1, n1;      // (zero end velocities: only n0 = 4v and n1 = 2v are kept -- m0 = -n1 and m1 = -n0 are sign modifiers at their uses, not values)
+    template <class P> __device__ __forceinline__ T M0() const { if constexpr (P::zero_vel) return -n1; else return m0; }
+    template <class P> __device__ __forceinline__ T M1() const { if constexpr (P::zero_vel) return -n0; else return m1; }
 };
+// A small constant held in a scalar register: as a literal a multiply-add has to be the two-address form, which overwrites its
+// addend -- and the addends here (the velocity combinations) are needed again, so each would be copied first.
+template <typename T> __device__ __forceinline__ T scalar_const(T c)
+{
+    asm("" : "+s"(c));
+    return c;
+}
 
 // What a lane carries from one step to the next: the reciprocals and the four accelerations.
 // GT = false: the time derivatives are rebuilt at the start of the step (14 flop) -- eight registers that are then free in
@@ -237,7 +246,8 @@ template <> struct CMap<4> { static constexpr int NC = 4; };   // onedpath2_ip.c
 
 // accelerations only: enough for constraintsSatisfied (onedpath_ip.cpp:738-751)
 // (kdx0, kdx1: the problem's two deltas, passed in by callers that have read them from LDS together with other values)
-template <typename T, class P>
+// KEEP: the caller carries x on (the in-place step), so the constants come from scalar registers (scalar_const)
+template <typename T, class P, bool KEEP = true>
 __device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, PointAux<T> &x, T kdx0, T kdx1)
 {
     const T rr = rcp_(t0 * t1);                               // one reciprocal for both durations: 1/t0 = t1/(t0 t1)
@@ -246,45 +256,48 @@ __device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<
     e.r1 = r1;
     x.u0 = kdx0 * r0;                                         // dX / t
     x.u1 = kdx1 * r1;
-    x.m0 = seg0_m<T>(k, v); x.n0 = seg0_n<T>(k, v);           // segment 0: v1 = vel1
-    x.m1 = seg1_m<T>(k, v); x.n1 = seg1_n<T>(k, v);           // segment 1: v0 = vel1
-    e.a[0] = fma_(T(6), x.u0, x.m0) * r0;
-    e.a[1] = fma_(T(-6), x.u0, x.n0) * r0;
-    e.a[2] = fma_(T(6), x.u1, x.m1) * r1;
-    e.a[3] = fma_(T(-6), x.u1, x.n1) * r1;
+    x.n0 = seg0_n<T>(k, v);                                   // segment 0: v1 = vel1
+    x.n1 = seg1_n<T>(k, v);                                   // segment 1: v0 = vel1
+    if constexpr (!P::zero_vel) { x.m0 = seg0_m<T>(k, v); x.m1 = seg1_m<T>(k, v); }
+    const T six = KEEP ? scalar_const(T(6)) : T(6);
+    e.a[0] = fma_(six, x.u0, x.template M0<P>()) * r0;
+    e.a[1] = fma_(-six, x.u0, x.n0) * r0;
+    e.a[2] = fma_(six, x.u1, x.template M1<P>()) * r1;
+    e.a[3] = fma_(-six, x.u1, x.n1) * r1;
 }
-template <typename T, class P>
+template <typename T, class P, bool KEEP = true>
 __device__ __forceinline__ void accel_values_u(const P &k, T v, T t0, T t1, Acc<T> &e, PointAux<T> &x)
 {
     const T kdx0 = k.dx0, kdx1 = k.dx1;      // (read first: from LDS in the in-place kernels, under the reciprocal)
-    accel_values_u(k, v, t0, t1, e, x, kdx0, kdx1);
+    accel_values_u<T, P, KEEP>(k, v, t0, t1, e, x, kdx0, kdx1);
 }
 template <typename T, class P>
 __device__ __forceinline__ void accel_values(const P &k, T v, T t0, T t1, Acc<T> &e)
 {
     PointAux<T> x;
-    accel_values_u(k, v, t0, t1, e, x);
+    accel_values_u<T, P, false>(k, v, t0, t1, e, x);
 }
 
 // first derivatives, from the reciprocals already in e (dAdT, dAdV0/dAdV1 of :389-391, :430-432) and what the values left behind
-template <typename T>
+template <typename T, class P, bool KEEP = true>
 __device__ __forceinline__ void accel_grads_u(Acc<T> &e, const PointAux<T> &x)
 {
     const T r0 = e.r0, r1 = e.r1;
     const T q0 = r0 * r0, q1 = r1 * r1;
-    e.gt[0] = fma_(T(-12), x.u0, -x.m0) * q0;
-    e.gt[1] = fma_(T(12), x.u0, -x.n0) * q0;
-    e.gt[2] = fma_(T(-12), x.u1, -x.m1) * q1;
-    e.gt[3] = fma_(T(12), x.u1, -x.n1) * q1;
+    const T twelve = KEEP ? scalar_const(T(12)) : T(12);
+    e.gt[0] = fma_(-twelve, x.u0, -x.template M0<P>()) * q0;
+    e.gt[1] = fma_(twelve, x.u0, -x.n0) * q0;
+    e.gt[2] = fma_(-twelve, x.u1, -x.template M1<P>()) * q1;
+    e.gt[3] = fma_(twelve, x.u1, -x.n1) * q1;
 }
 template <typename T, class P>
 __device__ __forceinline__ void accel_grads(const P &k, T v, Acc<T> &e)
 {
     PointAux<T> x;
     x.u0 = k.dx0 * e.r0; x.u1 = k.dx1 * e.r1;
-    x.m0 = seg0_m<T>(k, v); x.n0 = seg0_n<T>(k, v);
-    x.m1 = seg1_m<T>(k, v); x.n1 = seg1_n<T>(k, v);
-    accel_grads_u(e, x);
+    x.n0 = seg0_n<T>(k, v); x.n1 = seg1_n<T>(k, v);
+    if constexpr (!P::zero_vel) { x.m0 = seg0_m<T>(k, v); x.m1 = seg1_m<T>(k, v); }
+    accel_grads_u<T, P, false>(e, x);
 }
 
 // second derivatives (evalAccelSecondDerivInit / Final, onedpath_ip.cpp:394-411, 435-452)
@@ -719,7 +732,7 @@ __device__ __forceinline__ void direction(const P &k, const KParams<T> &kp, T v,
             T m0d, n0d, m1d, n1d;      // 2 m0, 2 n0, 2 m1, 2 n1 of accel_values
             if constexpr (HAVE_C) {      // ... which the carried evaluation of this very point has left behind (same products: same bits)
                 u0 = aux->u0; u1 = aux->u1;
-                if constexpr (P::zero_vel) { m0d = aux->m1; n0d = aux->n0 + aux->n0; m1d = -n0d; n1d = aux->n0; }      // -4v, 8v, -8v, 4v
+                if constexpr (P::zero_vel) { m0d = -aux->n0; n0d = aux->n0 + aux->n0; m1d = -n0d; n1d = aux->n0; }      // -4v, 8v, -8v, 4v
                 else { m0d = T(2) * seg0_m<T>(k, v); n0d = T(2) * seg0_n<T>(k, v); m1d = T(2) * seg1_m<T>(k, v); n1d = T(2) * seg1_n<T>(k, v); }      // (four more values to carry: no registers)
             } else {
                 u0 = k.dx0 * r0; u1 = k.dx1 * r1;
@@ -1575,7 +1588,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
         bool used = false;
         [[maybe_unused]] bool frozen = false;      // FROZEN: the trial point has become bitwise x (and stays so: s only shrinks)
         for (;;) {
-            accel_grads_u(et, xt);
+            accel_grads_u<T, P>(et, xt);
             residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);      // (r0n and the direction have taken what they needed from c)
             const T rn = residual_from_sums<T, NC>(c.X, c.Q1, c.Q2, p);
             diag.moving();
@@ -1620,7 +1633,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
             if (__builtin_amdgcn_ballot_w64(frozen) != 0ull) {
                 used = true;
                 if (frozen) {
-                    accel_grads_u(et, xt);      // (the loop above may have been left before it came round to this trial)
+                    accel_grads_u<T, P>(et, xt);      // (the loop above may have been left before it came round to this trial)
                     AffineResidual<T, VARIANT> ar;
                     ar.setup(et, [&](int i) { return (T)bk.get(3 + i); }, dl, p, L);
                     ar.search(kp, ar(T(0)), s, it, diag);

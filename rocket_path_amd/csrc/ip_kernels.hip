@@ -164,7 +164,7 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) e.a[j] = e0.a[j];
         if constexpr (GATED || INPLACE) {
-            accel_grads_u(e0, x0);
+            accel_grads_u<T, P>(e0, x0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) e.gt[j] = e0.gt[j];
             if constexpr (Carry::has_sums) {
