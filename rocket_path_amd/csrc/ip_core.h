@@ -643,7 +643,7 @@ __device__ __forceinline__ void solve_arrow(T a, T b, T c, T d, T e, T rv, T r0,
     const T alpha = HALF ? T(2.0 * 0.6403882032022076) : T(0.6403882032022076);
     const T de = d * e;
     // (one flag from four comparisons: written with && the compiler branches on the first and evaluates it twice, once negated)
-    const bool bounded = (abs_(d) >= alpha * abs_(b)) & (abs_(e) >= alpha * abs_(c)) & (de != T(0)) & finite_(de);
+    const bool bounded = (int)(abs_(d) >= alpha * abs_(b)) & (int)(abs_(e) >= alpha * abs_(c)) & (int)(de != T(0)) & (int)finite_(de);
     if (bounded) {
         const T ide = rcp_(de);                              // one reciprocal for both pivots: 1/d = e/(d e)
         const T id = e * ide, ie = d * ide;
