@@ -976,6 +976,40 @@ template <typename T, int VARIANT> struct AffineResidual {
         const T rv = fma_(rv1, sq, rv0), ra = fma_(ra1, sq, ra0), rb = fma_(rb1, sq, rb0);
         return (accm + accp) + fma_(rb, rb, fma_(ra, ra, rv * rv));
     }
+    // How many of the next trials (s, s/2, s/4, ...) FAIL the residual test beyond doubt -- counted, not evaluated.  In exact
+    // arithmetic the affine model's value is R(s) = R(0) + B s + C s^2 with B = 2 S r_i(0) r_i', C = S r_i'^2 >= 0, and the test
+    // "R(s) <= R(0) (1 - armijo s)" fails iff s (B + armijo R(0) + C s) > 0.  The evaluation (operator()) is a sum of squares of
+    // singly rounded terms: its relative error is below 10 u (u = eps / 2), the bound's below 14 u, B's absolute error below
+    // 13 u Babs (Babs = 2 S |r_i(0) r_i'|), C's relative error below 13 u.  So wherever
+    //     h(s) = s (B + armijo R(0)) + C s^2 - 64 eps (R(0) + s Babs + C s^2) > 0
+    // -- a margin four times the sum of those errors -- the evaluated test fails as well.  h(0) < 0 and h is convex, so h > 0
+    // exactly on the step lengths above its positive root: "h(s 2^-k) > 0" is true up to some k and false from there on, and
+    // seven probes of a bisection find the count K in [0, 127]: every counted trial lies between two probes at which h > 0 was
+    // EVALUATED.  The reference's loop halves ~50-60 times per post-convergence step before s r' drops below the rounding of r;
+    // all but the last few of those halvings are decided here in ~80 instructions instead of ~27 each.  (Backtrack factor 1/2
+    // only; a NaN anywhere makes every comparison false: K = 0.)
+    __device__ __forceinline__ int certain_failures(const KParams<T> &kp, T r0, T s) const
+    {
+        constexpr T eps = sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-7);
+        constexpr T margin = T(64) * eps;
+        T B = rv0 * rv1, Babs = abs_(B), C = rv1 * rv1;
+        B = fma_(ra0, ra1, B); Babs = fma_(abs_(ra0), abs_(ra1), Babs); C = fma_(ra1, ra1, C);
+        B = fma_(rb0, rb1, B); Babs = fma_(abs_(rb0), abs_(rb1), Babs); C = fma_(rb1, rb1, C);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            B = fma_(c0[i], c1[i], B);
+            Babs = fma_(abs_(c0[i]), abs_(c1[i]), Babs);
+            C = fma_(c1[i], c1[i], C);
+        }
+        const T h0 = -margin * r0;
+        const T h1 = fma_(kp.armijo, r0, B + B) - margin * (Babs + Babs);
+        const T h2 = C * (T(1) - T(2) * margin);
+        auto holds = [&](T q) { return fma_(fma_(h2, q, h1), q, h0) > T(0); };
+        int last = 0;
+#pragma unroll
+        for (int b = 64; b >= 1; b >>= 1) last += holds(ldexp_(s, -(last + b))) ? b : 0;
+        return holds(s) ? last + 1 : 0;
+    }
     // The reference's loop from trial number `it` on (s is that trial's step length, not yet tested): W step lengths per trip
     // (s and its next W - 1 halvings), accepted in the reference's order.  A lone wave on its SIMD is bound by the latency of
     // one evaluation's dependent chain; all W evaluations are complete before the one branch of the trip, so they fill each
@@ -1638,7 +1672,22 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                     accel_grads_u<T, P>(et, xt);      // (the loop above may have been left before it came round to this trial)
                     AffineResidual<T, VARIANT> ar;
                     ar.setup(et, [&](int i) { return (T)bk.get(3 + i); }, dl, p, L);
-                    ar.search(kp, ar(T(0)), s, it, diag);
+                    const T r0a = ar(T(0));
+#ifndef RP_FROZEN_PROOF
+#define RP_FROZEN_PROOF 1      // 0: every trial of the frozen search is evaluated (A/B builds: no decision may change)
+#endif
+                    if (RP_FROZEN_PROOF && kp.backtrack == T(0.5)) {
+                        // the trials that fail beyond doubt, counted in closed form (AffineResidual::certain_failures)
+                        int skip = ar.certain_failures(kp, r0a, s);
+                        const int room = kp.max_bt - it;
+                        skip = skip < room ? skip : room;
+                        skip = skip > 0 ? skip : 0;
+                        s = ldexp_(s, -skip);
+                        it += skip;
+                        if constexpr (!std::is_same<D, NoDiag>::value)
+                            for (int q = 0; q < skip; ++q) diag.resid();
+                    }
+                    ar.search(kp, r0a, s, it, diag);
 #pragma unroll
                     for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, bk.get(3 + i));
                     residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);
