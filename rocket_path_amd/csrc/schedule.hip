@@ -55,9 +55,9 @@ constexpr int kCountPerThread = kTileProblems / kCountThreads;
 constexpr int kWaves = kThreads / 64;
 constexpr int kWaveSpan = kTileProblems / kWaves;         // consecutive problems a wave owns: 1,024 = 16 groups of 64
 
-// key = ratio class (6 bits) : length level (6 bits).  Level = 8 per octave of the longer segment's length from 4 upwards
-// (exponent and top three mantissa bits of its float pattern), clamped to [0, 63].  Equal segments, zero-length pairs and
-// NaN go to the last class; a reversal (segments of opposite sign) has key 0.
+// key = ratio class (6 bits) : length level (kLevelBits = 5 bits).  Level = 4 per octave of the longer segment's length from 4
+// upwards (exponent and top two mantissa bits of its float pattern), clamped to [0, 31].  Equal segments, zero-length pairs
+// and NaN go to the last class; a reversal (segments of opposite sign) has key 0.
 __device__ __forceinline__ uint32_t schedule_key(double p0, double p1, double p2)
 {
     if ((p1 - p0) * (p2 - p1) < 0.0) return 0u;
@@ -155,7 +155,7 @@ k_sched_scan(uint32_t *__restrict__ hist, unsigned ntiles, uint32_t *__restrict_
     }
 }
 
-// lanes of the wave that hold the same 12-bit key as this lane
+// lanes of the wave that hold the same key (kKeyBits = 11 bits) as this lane
 __device__ __forceinline__ unsigned long long match_key(uint32_t key)
 {
     unsigned long long peers = ~0ull;
@@ -253,7 +253,7 @@ inline unsigned tiles_for(size_t n) { return (unsigned)((n + kTileProblems - 1) 
 
 }  // namespace
 
-// scratch layout: hist[tiles][4096] | total[4096] | keys[n] (16 bit)
+// scratch layout: hist[tiles][kKeys] | total[kKeys] | keys[n] (16 bit)
 hipError_t schedule_scratch_bytes(size_t n, size_t *bytes)
 {
     *bytes = align256((size_t)tiles_for(n) * kKeys * sizeof(uint32_t)) + kKeys * sizeof(uint32_t) + align256(n * sizeof(uint16_t));
