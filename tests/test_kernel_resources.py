@@ -34,8 +34,9 @@ def test_headline_kernels_fit_their_waves_without_scratch():
     # the benchmark's kernel k_solve_chunks<double, double, 3, STALL=false, ZV=true, MU=0, START=false>, its START=true twin (a
     # fresh batch's first solve) and its fixed-step sibling k_steps_chunks<double, double, 3, ZV=true>
     gated = {k: v for k, v in usage.items() if "k_solve_chunksIddLi3ELb0ELb1ELi0E" in k}
-    fixed = {k: v for k, v in usage.items() if "k_steps_chunksIddLi3ELb1E" in k}
-    assert len(gated) == 2 and len(fixed) == 1, sorted(usage)
+    fixed = {k: v for k, v in usage.items() if "k_steps_chunksIddLi3ELb1ELb0E" in k}      # ... with the step's start in LDS (large batches)
+    small = {k: v for k, v in usage.items() if "k_steps_chunksIddLi3ELb1ELb1E" in k}      # ... in registers (batches below three waves per SIMD)
+    assert len(gated) == 2 and len(fixed) == 1 and len(small) == 1, sorted(usage)
     for k, v in list(gated.items()) + list(fixed.items()):
         assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0, (k, v)
     for k, v in gated.items():
@@ -45,6 +46,8 @@ def test_headline_kernels_fit_their_waves_without_scratch():
     for k, v in fixed.items():      # round 4: F3's fixed-step launches step in place like the gated solve -- same budget, same LDS column
         assert v["VGPRs"] <= 128, (k, v)
         assert v["LDS Size [bytes/block]"] == 13 * 64 * 8, (k, v)
+    for k, v in small.items():
+        assert v["VGPRs"] <= 168 and v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0 and v["LDS Size [bytes/block]"] == 0, (k, v)
     # the k = 1 streaming launch (two problems per lane, 14 x 16 B of fields in registers next to the step) fits three waves per SIMD
     k1 = {k: v for k, v in usage.items() if "k_newton_stream16IddLi3ELb1E" in k}
     assert len(k1) == 1
