@@ -67,6 +67,24 @@ def test_allreduce_summary_single_process_is_identity():
         sharding.allreduce_summary(torch.zeros(3, dtype=torch.float64))
 
 
+def test_forced_collectives_in_a_group_of_one_rank_are_the_identity():
+    # bench.py --force-process-group: the summary goes through the backend's all-reduces even at world size 1 (on the GPU box:
+    # RCCL; here: gloo, in a child process so that this process keeps no process group)
+    import subprocess
+    import sys
+    code = ("import os, sys, torch, torch.distributed as dist\n"
+            "sys.path.insert(0, %r)\n"
+            "from rocket_path_amd import sharding\n"
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=%r)\n"
+            "dist.init_process_group('gloo', rank=0, world_size=1)\n"
+            "t = torch.tensor([1.5, -2.0, 3.0, 4.0], dtype=torch.float64)\n"
+            "assert sharding.allreduce_summary(t.clone(), force=True).tolist() == t.tolist()\n"
+            "assert sharding.allreduce_summary(t.clone()).tolist() == t.tolist()\n"
+            "dist.barrier(); dist.destroy_process_group(); print('forced ok')\n") % (os.path.dirname(HERE), str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "forced ok" in r.stdout, r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_summary_equals_whole_batch(world, oracle):
     n_total = 601     # not divisible: ragged shards
