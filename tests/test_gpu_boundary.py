@@ -577,7 +577,8 @@ def test_static_storage_drop_in_runs_and_tears_down_after_main(golden_dir):
     kat = json.load(open(os.path.join(golden_dir, "survey_kat.json")))
     out = subprocess.run([exe, "--keys", "i n s n s n13 s HOME n SPACE F4 n s F3 s"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
-    assert out.stderr == "", out.stderr[-2000:]                         # nothing from the keys, nothing from the destructors
+    noise = [l for l in out.stderr.splitlines() if l.strip() and "amdgpu.ids" not in l]      # (libdrm's complaint about a missing id table is the image's, not ours)
+    assert noise == [], out.stderr[-2000:]                              # nothing from the keys, nothing from the destructors
     states = [list(map(float, l.split()[1:])) for l in out.stdout.splitlines() if l.startswith("State17:")]
     assert len(states) == 5
     assert serr(states[0], kat["f3_default"]["after_step_1"]) < 1e-11
