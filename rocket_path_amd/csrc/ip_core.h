@@ -40,9 +40,13 @@
 //    divides by t about 20 times per constraint sweep, onedpath_ip.cpp:385-391, 404-410), one for all
 //    constraints, one for the two arrow pivots, one for the boundary fraction -- 4-5 per step where the first
 //    version of this file had 19.  Define RP_EXACT_DIV to build with correctly rounded divisions instead (A/B builds).
-//  * template switches of newton_step: MEMO (fixed-step kernels: exact memoisation for the
-//    reference's post-convergence regime), AFFINE (with MEMO: that regime's residual loop on affine
-//    pieces), MU (rp_params.mu_mode), a bookkeeping hook (halving counts for rp_batch_step_counted).
+//  * two forms of the step.  newton_step_inplace (the gated solve, and since round 4 every fixed-step launch of F3): the trial
+//    overwrites the state, the step's start waits in LDS (or, for small batches, registers), residual sums carried, loops tested
+//    by ballots over comparisons; FROZEN adds the post-convergence regime's search on affine pieces with its certain failures
+//    counted in closed form.  newton_step_to (F4's fixed-step launches, mu_mode 1): template switches MEMO (exact memoisation
+//    for the reference's post-convergence regime), AFFINE (with MEMO: that regime's residual loop on affine pieces), MU
+//    (rp_params.mu_mode), WAVE (stragglers of the residual loop served by the whole wave).  Both take a bookkeeping hook
+//    (halving counts for rp_batch_step_counted).
 #pragma once
 
 #include <hip/hip_runtime.h>

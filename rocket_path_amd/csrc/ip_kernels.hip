@@ -18,12 +18,14 @@
 //   k_solve_chunks     the gated solve (the benchmark's kernel): one 64-problem chunk of the scheduled order per
 //                      single-wave block, state in registers from its first load to its last store (LDS only as the in-place
 //                      step's backup column, no staging), longest chunks dispatched first
-//   k_steps_chunks     k >= 2 ungated steps: the same shape, fixed step count
+//   k_steps_chunks     k >= 2 ungated steps: the same shape, fixed step count.  F3 runs the gated solve's in-place step here too
+//                      (round 4; below three waves per SIMD an instantiation that keeps the step's start in registers); F4 keeps
+//                      newton_step_to with the wave-parallel line search -- a wave's stragglers in the residual loop are served
+//                      by the whole wave
 //   k_newton_stream16  k = 1 (one launch per Newton step), the HBM-streaming form: 16 B per lane (two doubles / four floats =
 //                      that many consecutive problems per lane), one global_load/store_dwordx4 per field
 //   k_newton_stream    the same with one problem per lane and a register prefetch: ragged remainders, mu_mode 1
-//                      (F4: with the wave-parallel line search of newton_step_to -- a wave's stragglers in the residual loop
-//                      are served by the whole wave; round 2's LDS-regrouping kernel for F4 is gone, this is faster)
+// Every fixed-step kernel of a variant runs the same step function, so step(k) is k x step(1) bit for bit in every shape.
 // Problems are independent and nothing is re-read, so there is no L2 locality to arrange: consecutive blocks are dealt
 // round-robin over the 8 XCDs and touch disjoint cache lines.
 #include "ip_kernels.h"
@@ -103,15 +105,14 @@ __device__ __forceinline__ void store_solution(Solution *rec, double v, double t
 #define RP_NEWTON_WAVES 2     // minimum waves per SIMD the register allocator must leave room for
 #endif
 #ifndef RP_GATED_WAVES
-#define RP_GATED_WAVES 4     // 128 VGPRs: the in-place step with the cold values parked in LDS fits without a spill in the loop; 1 Mi problems = 16,384
+#define RP_GATED_WAVES 4     // 128 VGPRs (112-128 used): the in-place step with the cold values parked in LDS fits without a spill in the loop; 1 Mi problems = 16,384
                              // waves = exactly four full rounds of the chip's 4,096 wave slots (three per SIMD: 5.33 rounds).  The stall-detector
                              // twin (two more live values, 10 spilled at 128) stays at three
 #endif
 // Which residual-loop form the fixed-step kernels use once the trial point has become x (newton_step's AFFINE): every kernel of
-// a variant uses the same one, so that all launch shapes agree bit for bit.  F4 reaches that regime within a dozen steps
-// (its stalled problems) and has the registers: affine pieces.  F3 reaches it only after convergence (step ~20 of a fixed-step
-// run); the 44 registers of the pieces would cost every F3 fixed-step kernel a wave per SIMD (k_newton_stream16: 200 -> 3 waves
-// instead of 2), which the HBM-streaming k = 1 launch of a live solve needs more than a converged batch needs cheap halvings.
+// a variant uses the same one, so that all launch shapes agree bit for bit.  This switch concerns newton_step_to, i.e. F4 (affine
+// pieces: it reaches that regime within a dozen steps and has the registers) and mu_mode 1; since round 4 F3's fixed-step
+// launches run newton_step_inplace<FROZEN>, whose post-convergence search is on affine pieces as well (ip_core.h).
 #ifdef RP_AFFINE_ALL      // A/B build (profiles/r3_tuning.md: no gain for F3, 168 VGPRs + 2 spilled in its chunk kernel)
 template <int VARIANT> constexpr bool kAffine = true;
 #else
@@ -124,7 +125,7 @@ template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
 #define RP_GATED_IN_PLACE 1     // the gated kernel's step overwrites the state, its start backed up in LDS (0: newton_step_to, for A/B runs)
 #endif
 #ifndef RP_TILED_WAVES
-#define RP_TILED_WAVES 3     // the fixed-step large-batch kernels fit 168 VGPRs (152-166); the gated solve has its own bound, RP_GATED_WAVES
+#define RP_TILED_WAVES 3     // F4's fixed-step chunk kernels (156-168 VGPRs) and F3's register-column instantiation; the in-place kernels have RP_GATED_WAVES
 #endif
 
 // The per-lane body shared by both Newton kernels: up to k steps on the state held in registers.
