@@ -22,4 +22,6 @@ RP_BATCH_LIB=$P/librp_batch_diag_moving.so python profiles/probes/moving_stats_p
 { export RP_BATCH_LIB=$P/librp_batch_tuning.so; echo "== k_newton_stream16 (shipped choice)"; python profiles/probes/k1_ab_probe.py | tail -6; echo "== k_steps_chunks from k = 1 (RP_CHUNKS_FROM_K=1)"; RP_CHUNKS_FROM_K=1 python profiles/probes/k1_ab_probe.py | tail -6; echo "== k_newton_stream, 8 B per lane (RP_STREAM_SCALAR=1)"; RP_STREAM_SCALAR=1 python profiles/probes/k1_ab_probe.py | tail -6; unset RP_BATCH_LIB; } > $O/k1_ab.log 2>&1
 python profiles/probes/solution_probe.py > $O/solution_probe.log 2>&1
 python profiles/probes/f4_speed_probe.py > $O/f4_speed.log 2>&1
+# 1.44 M fresh, distinct gated solves (and 12 fixed steps of the same problems) against the oracle
+python tests/checks/fuzz_parity.py > $O/fuzz_parity.log 2>&1
 echo probes collected
