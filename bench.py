@@ -647,8 +647,8 @@ def main():
                                    "feasibility halvings and up to 33 residual halvings per step from step ~6 on: F4 stalls, "
                                    "README.md:34), which is why a fused step costs several times a k = 1 step"}
 
-        # (d) the rows either side of the path: the plot-data kernel on a solved batch (66 positions + 4 accelerations per
-        #     problem into device memory: 48 B of state + 4 B of slot map read, 560 B written) and the feasibility move
+        # (d) the rows either side of the path: the plot data of a solved batch (66 positions + 4 accelerations per
+        #     problem into device memory: 48 B of state and positions used, 560 B written) and the feasibility move
         #     (moveTowardFeasibility, the Space key) on the same number of starts pushed out of the feasible set
         with rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) as c6:
             c6.set_problems_device(*ptrs)
@@ -697,14 +697,15 @@ def main():
                             "not traffic-bound"}
 
         line["neighbours"] = {
-            "workload": "SURVEY 8f rows 1 and 3: plot data of %d solved problems into device memory (k_sample); feasibility move of %d infeasible "
+            "workload": "SURVEY 8f rows 1 and 3: plot data of %d solved problems into device memory (rp_batch_sample_device); feasibility move of %d infeasible "
                         "starts (k_feasibility_move: four violated rows each, the rank-deficient branch of the QR)" % (count, n7),
             "sample": {"ms": t_s, "problems_per_s": count / (t_s * 1e-3),
                        "roofline": {"bound": "hbm", "bytes_moved_per_problem": b_sample, "achieved": b_sample * count / (t_s * 1e-3) / 1e9,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_sample * count / (t_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "note": "output rows are in problem order, the state in scheduled order: the six fields are gathered, one "
-                                            "32-byte sector each (192 B of read traffic per problem for 48 B used); on 756 B of sector traffic the "
-                                            "same launch is %.0f GB/s" % (756.0 * count / (t_s * 1e-3) / 1e9)}},
+                                    "note": "output rows are in problem order, the state in scheduled order: a whole batch whose positions are the ones it was "
+                                            "given goes through problem-order records (k_solution: 68 B per problem, then k_sample_records: 64 B read, 560 B "
+                                            "written) instead of gathering six 32-byte sectors per problem; on those 692 B the two launches together are "
+                                            "%.0f GB/s" % (692.0 * count / (t_s * 1e-3) / 1e9)}},
             "feasibility_move": {"ms": t_f, "problems_per_s": n7 / (t_f * 1e-3),
                                  "hbm_GBps_on_136_B_per_problem": 136.0 * n7 / (t_f * 1e-3) / 1e9,
                                  "roofline": feas_roofline(t_f, n7),

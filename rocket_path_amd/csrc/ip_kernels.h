@@ -95,6 +95,9 @@ hipError_t launch_gather_u32(const BatchView &b, const uint32_t *d_src, uint32_t
 // the rows either side of the hot path
 hipError_t launch_move_toward_feasibility(const BatchView &b, const HostParams &hp, hipStream_t stream);
 hipError_t launch_sample(const BatchView &b, double *d_pos66, double *d_acc4, hipStream_t stream);
+// the same for a whole scheduled batch with zero end velocities whose b.records still hold its positions: through problem-order
+// records (solution records written into d_solution_scratch, n of them, first) instead of the gather through slot_of
+hipError_t launch_sample_from_records(const BatchView &b, Solution *d_solution_scratch, double *d_pos66, double *d_acc4, hipStream_t stream);
 
 // the same for problems [first, first + count), plus printState's constraint table (1 + 14 m doubles per problem)
 hipError_t launch_soa_to_aos_range(const BatchView &b, size_t first, size_t count, double *d_aos, hipStream_t stream);

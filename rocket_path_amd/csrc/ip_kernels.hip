@@ -1109,6 +1109,58 @@ k_sample(const T *__restrict__ base, size_t stride, size_t first, size_t count, 
     for (int o = threadIdx.x; o < here * 4; o += kBlock) out_acc[o] = s_acc[o & 3][o >> 2];
 }
 
+// The same plot data for a WHOLE scheduled batch from two problem-order records per problem (round 4): the positions the batch
+// was given (StartRecord, kept by the scheduling pass) and the problem's solution record (k_solution writes them into a scratch
+// first: 68 B per problem).  Both reads are coalesced whole sectors -- 64 B per problem where the gather through slot_of touches
+// six 32-byte sectors for 48 B -- and the arithmetic and the stores are k_sample's (same bits).  Zero end velocities only, and
+// only while the records are the batch's positions (rp_batch.cpp keeps the flag).
+template <typename S>
+__global__ void __launch_bounds__(kBlock)
+k_sample_records(const StartRecord *__restrict__ records, const Solution *__restrict__ sol, size_t count,
+                 double *__restrict__ pos66, double *__restrict__ acc4)
+{
+    __shared__ double s_seg[2][6][kSampleProblems];      // per segment: x0, x1, va, acc0, jrk0, h / 32
+    __shared__ double s_acc[4][kSampleProblems];
+    const size_t p_first = (size_t)blockIdx.x * kSampleProblems;
+    const int here = (int)(count - p_first < (size_t)kSampleProblems ? count - p_first : (size_t)kSampleProblems);
+    if (threadIdx.x < here) {
+        const int q = threadIdx.x;
+        typedef double v2 __attribute__((ext_vector_type(2)));
+        const v2 *rec = reinterpret_cast<const v2 *>(records + p_first + q), *so = reinterpret_cast<const v2 *>(sol + p_first + q);
+        const v2 ra = rec[0], rb = rec[1], sa = so[0], sb = so[1];
+        const double p0 = (double)(S)ra[0], p1 = (double)(S)ra[1], p2 = (double)(S)rb[0];      // what the constant fields hold
+        const double v1 = sa[0], t0 = sa[1], t1 = sb[0];
+#pragma unroll
+        for (int seg = 0; seg < 2; ++seg) {
+            const double x0 = seg ? p1 : p0, x1 = seg ? p2 : p1, va = seg ? v1 : 0.0, vb = seg ? 0.0 : v1, h = seg ? t1 : t0;
+            const double ih = rcp_<double>(h), ih2 = ih * ih;
+            const double acc0 = (x1 - x0) * (6.0 * ih2) - (va * 4.0 + vb * 2.0) * ih;
+            const double jrk0 = (vb - va) * (2.0 * ih2) - acc0 * (2.0 * ih);
+            s_seg[seg][0][q] = x0; s_seg[seg][1][q] = x1; s_seg[seg][2][q] = va;
+            s_seg[seg][3][q] = acc0; s_seg[seg][4][q] = jrk0; s_seg[seg][5][q] = h * 0.03125;
+            s_acc[2 * seg][q] = ((x1 - x0) * 6.0 * ih + va * -4.0 + vb * -2.0) * ih;
+            s_acc[2 * seg + 1][q] = ((x1 - x0) * -6.0 * ih + va * 2.0 + vb * 4.0) * ih;
+        }
+    }
+    __syncthreads();
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    auto position = [&](int q, int slot) -> double {
+        const int seg = slot >= 33, j = slot - 33 * seg;
+        if (j == 0) return s_seg[seg][0][q];
+        if (j == 32) return s_seg[seg][1][q];
+        const double t = s_seg[seg][5][q] * (double)j;      // h j / 32
+        return s_seg[seg][0][q] + (s_seg[seg][2][q] + (s_seg[seg][3][q] + s_seg[seg][4][q] * (t * (1.0 / 3.0))) * (t * 0.5)) * t;
+    };
+    v2 *out_pos = reinterpret_cast<v2 *>(pos66 + p_first * 66);
+    for (int pr = threadIdx.x; pr < here * 33; pr += kBlock) {
+        const int q = pr / 33, pair = pr - q * 33;
+        const v2 both = {position(q, 2 * pair), position(q, 2 * pair + 1)};
+        __builtin_nontemporal_store(both, out_pos + pr);
+    }
+    double *out_acc = acc4 + p_first * 4;
+    for (int o = threadIdx.x; o < here * 4; o += kBlock) out_acc[o] = s_acc[o & 3][o >> 2];
+}
+
 // printState's per-problem part for a (small) range of problems: the surrogate gap and, per constraint, what
 // printConstraints shows (onedpath_ip.cpp:955-995, 1008-1010): error, gradient, the 3x3 second-derivative
 // matrix and dot = (0,-1,-1).gradient.  Row layout per problem, in doubles:
@@ -1477,6 +1529,18 @@ hipError_t launch_sample_range(const BatchView &b, size_t first, size_t count, d
 }
 
 hipError_t launch_sample(const BatchView &b, double *d_pos66, double *d_acc4, hipStream_t stream) { return launch_sample_range(b, 0, b.n, d_pos66, d_acc4, stream); }
+
+hipError_t launch_sample_from_records(const BatchView &b, Solution *d_solution_scratch, double *d_pos66, double *d_acc4, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    if (!b.scheduled || !b.zero_end_vel || !b.records) return hipErrorInvalidValue;
+    hipError_t e = launch_solution(b, d_solution_scratch, stream);      // every problem's (vel1, duration0, duration1) in problem order
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)((b.n + kSampleProblems - 1) / kSampleProblems));
+    if (b.dtype == 0) hipLaunchKernelGGL((k_sample_records<double>), grid, dim3(kBlock), 0, stream, (const StartRecord *)b.records, (const Solution *)d_solution_scratch, b.n, d_pos66, d_acc4);
+    else              hipLaunchKernelGGL((k_sample_records<float>), grid, dim3(kBlock), 0, stream, (const StartRecord *)b.records, (const Solution *)d_solution_scratch, b.n, d_pos66, d_acc4);
+    return hipGetLastError();
+}
 
 hipError_t launch_constraint_table(const BatchView &b, const HostParams &hp, size_t first, size_t count, double *d_rows, hipStream_t stream)
 {
