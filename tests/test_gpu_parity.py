@@ -417,35 +417,34 @@ def test_sample_against_oracle(oracle, g3):
 
 
 def test_sample_into_device_memory_equals_the_host_read_back():
-    import ctypes
-    rp.load_library()
-    # the HIP runtime the product library runs on (torch, if some other test imported it, brings a second copy)
-    paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}, key=lambda p: "torch" in p)
-    hip = ctypes.CDLL(paths[0])
+    from hip_util import DeviceBuffer
     n = 3 * 4096 + 17                                            # ragged last block of the kernel (128 problems per block)
     p0, p1, p2 = rp.problems.generate(606, 0, n, rp.problems.DIST_MONOTONE)
-    with rp.Batch(n) as b:
+    with rp.Batch(n) as b, DeviceBuffer(n * 66 * 8, fill=0xff) as d_pos, DeviceBuffer(n * 4 * 8, fill=0xff) as d_acc:
         b.set_problems(p0, p1, p2)
         b.solve(1e-8, 200, 0)
         pos, acc = b.sample()
-        d_pos, d_acc = ctypes.c_void_p(), ctypes.c_void_p()
-        assert hip.hipMalloc(ctypes.byref(d_pos), ctypes.c_size_t(n * 66 * 8)) == 0
-        assert hip.hipMalloc(ctypes.byref(d_acc), ctypes.c_size_t(n * 4 * 8)) == 0
-        try:
-            assert hip.hipMemset(d_pos, 0xff, ctypes.c_size_t(n * 66 * 8)) == 0 and hip.hipMemset(d_acc, 0xff, ctypes.c_size_t(n * 4 * 8)) == 0
-            b.sample_device(d_pos.value, d_acc.value)
-            b.sync()
-            got_pos, got_acc = np.empty((n, 66)), np.empty((n, 4))
-            assert hip.hipMemcpy(ctypes.c_void_p(got_pos.ctypes.data), d_pos, ctypes.c_size_t(n * 66 * 8), 2) == 0
-            assert hip.hipMemcpy(ctypes.c_void_p(got_acc.ctypes.data), d_acc, ctypes.c_size_t(n * 4 * 8), 2) == 0
-        finally:
-            hip.hipFree(d_pos)
-            hip.hipFree(d_acc)
-        assert np.array_equal(got_pos, pos) and np.array_equal(got_acc, acc)
+        b.sample_device(d_pos.ptr, d_acc.ptr)
+        # the device call takes a whole batch through problem-order records (k_solution + k_sample_records), the host call gathers
+        # field by field (k_sample): same bits
+        assert np.array_equal(d_pos.read(np.float64).reshape(n, 66), pos) and np.array_equal(d_acc.read(np.float64).reshape(n, 4), acc)
         # end points of the plot are the nodes themselves; the accelerations respect the limit at the solution
         st = b.get_state()
         assert np.array_equal(pos[:, 0], st[:, 11]) and np.array_equal(pos[:, 32], st[:, 13]) and np.array_equal(pos[:, 65], st[:, 14])
         assert np.abs(acc).max() <= 100.0 * (1 + 1e-12)
+        # once a position has been moved the records are no longer the batch's positions: the device call must gather as well
+        b.nudge(13, 10.0)                                        # Up key: pos1X += 10 for every problem
+        pos2, acc2 = b.sample()
+        b.sample_device(d_pos.ptr, d_acc.ptr)
+        assert np.array_equal(d_pos.read(np.float64).reshape(n, 66), pos2) and np.array_equal(d_acc.read(np.float64).reshape(n, 4), acc2)
+        assert np.array_equal(pos2[:, 32], pos[:, 32] + 10.0)
+        # ... and after new problems it goes through the records again (F4, fp32 state: the records' positions are rounded as the fields are)
+    with rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32_STATE) as b, DeviceBuffer(n * 66 * 8, fill=0xff) as d_pos, DeviceBuffer(n * 4 * 8, fill=0xff) as d_acc:
+        b.set_problems(p0, p1, p2)
+        b.step(7)
+        pos, acc = b.sample()
+        b.sample_device(d_pos.ptr, d_acc.ptr)
+        assert np.array_equal(d_pos.read(np.float64).reshape(n, 66), pos) and np.array_equal(d_acc.read(np.float64).reshape(n, 4), acc)
 
 
 def _violating_starts(oracle, variant, n, seed, four):
