@@ -179,6 +179,7 @@ template <typename T, bool ZV = false, bool LEAN = false> struct Prob {
 };
 // The same with the two deltas parked in LDS (the gated kernel, which needs its registers for a fourth wave per SIMD): a use is
 // a ds_read, which issues beside the arithmetic.  `at` points at this lane's value; volatile for the same reason as LdsBackup.
+template <typename T> using LdsBackup = __attribute__((address_space(3))) volatile T *;      // LDS address space kept in the type: ds_read / ds_write, not flat accesses
 template <typename T> struct LdsConst {
     __attribute__((address_space(3))) volatile T *at;
     __device__ __forceinline__ operator T() const { return *at; }
@@ -1307,16 +1308,41 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
                     const int src = __ffsll((long long)todo) - 1;
                     todo &= todo - 1ull;
                     P bk = k;
-                    bk.dx0 = bcast_(k.dx0, src);
-                    bk.dx1 = bcast_(k.dx1, src);
-                    if constexpr (!P::zero_vel) { bk.v0 = bcast_(k.v0, src); bk.v2 = bcast_(k.v2, src); }
-                    const T bv = bcast_(v, src), bt0 = bcast_(t0, src), bt1 = bcast_(t1, src);
-                    const T bdv = bcast_(dxv, src), bd0 = bcast_(dx0, src), bd1 = bcast_(dx1, src);
-                    const T bs = bcast_(s, src), bp = bcast_(p, src), br0n = bcast_(r0n, src);
+                    T bv, bt0, bt1, bdv, bd0, bd1, bs, bp, br0n, blam[NC], bdl[NC];
                     const int bit = bcast_(it, src);
-                    T blam[NC], bdl[NC];
+#ifndef RP_WAVE_BCAST_LDS
+#define RP_WAVE_BCAST_LDS 1      // the straggler's search state reaches the other lanes through LDS (0: 2 x 21 v_readlane, for A/B runs)
+#endif
+                    if constexpr (RP_WAVE_BCAST_LDS != 0) {
+                        // One lane writes its 13 + 2 NC values, every lane reads them back (a broadcast read: one address, no bank
+                        // conflict): LDS instructions, which issue beside the other waves' arithmetic, where 2 x 21 v_readlane and the
+                        // moves that bring their scalar results back into vector registers were a third of the service's vector
+                        // instructions.  The kernel's blocks are single waves (k_steps_chunks), and a wave's LDS operations complete in
+                        // order: no barrier.
+                        __shared__ T s_bc[13 + 2 * NC];
+                        LdsBackup<T> bc = (LdsBackup<T>)s_bc;
+                        if (lane_id == src) {
+                            bc[0] = k.dx0; bc[1] = k.dx1;
+                            if constexpr (!P::zero_vel) { bc[2] = k.v0; bc[3] = k.v2; }
+                            bc[4] = v; bc[5] = t0; bc[6] = t1; bc[7] = dxv; bc[8] = dx0; bc[9] = dx1; bc[10] = s; bc[11] = p; bc[12] = r0n;
 #pragma unroll
-                    for (int i = 0; i < NC; ++i) { blam[i] = bcast_(lam[i], src); bdl[i] = bcast_(dl[i], src); }
+                            for (int i = 0; i < NC; ++i) { bc[13 + i] = lam[i]; bc[13 + NC + i] = dl[i]; }
+                        }
+                        bk.dx0 = bc[0]; bk.dx1 = bc[1];
+                        if constexpr (!P::zero_vel) { bk.v0 = bc[2]; bk.v2 = bc[3]; }
+                        bv = bc[4]; bt0 = bc[5]; bt1 = bc[6]; bdv = bc[7]; bd0 = bc[8]; bd1 = bc[9]; bs = bc[10]; bp = bc[11]; br0n = bc[12];
+#pragma unroll
+                        for (int i = 0; i < NC; ++i) { blam[i] = bc[13 + i]; bdl[i] = bc[13 + NC + i]; }
+                    } else {
+                        bk.dx0 = bcast_(k.dx0, src);
+                        bk.dx1 = bcast_(k.dx1, src);
+                        if constexpr (!P::zero_vel) { bk.v0 = bcast_(k.v0, src); bk.v2 = bcast_(k.v2, src); }
+                        bv = bcast_(v, src); bt0 = bcast_(t0, src); bt1 = bcast_(t1, src);
+                        bdv = bcast_(dxv, src); bd0 = bcast_(dx0, src); bd1 = bcast_(dx1, src);
+                        bs = bcast_(s, src); bp = bcast_(p, src); br0n = bcast_(r0n, src);
+#pragma unroll
+                        for (int i = 0; i < NC; ++i) { blam[i] = bcast_(lam[i], src); bdl[i] = bcast_(dl[i], src); }
+                    }
                     const T sq = ldexp_(bs, -rank);                    // the step length of the serial loop's trial number bit + rank
                     const bool beyond = bit + rank >= kp.max_bt;       // ... which it would not make
                     const T qv = fma_(bdv, sq, bv), q0 = fma_(bd0, sq, bt0), q1 = fma_(bd1, sq, bt1);
@@ -1527,7 +1553,6 @@ __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T 
 // stored values to the reads (keeping them in registers is what this form is there to avoid) nor drops the stores.
 // The loops are written with the trial formed where s is set (at the bottom, from the backed-up start), so that a trial
 // is a multiply-add INTO the state registers.
-template <typename T> using LdsBackup = __attribute__((address_space(3))) volatile T *;      // LDS address space kept in the type: ds_read / ds_write, not flat accesses
 // Where the step's start waits: this lane's column of the block's LDS area (field q at p[q * 64]) -- the form the large-batch
 // kernels are built around, four waves per SIMD -- or, for batches too small to fill the chip (a lone wave per SIMD has nothing
 // to run under an LDS round trip: BASELINE configs[1]), plain registers at three.
