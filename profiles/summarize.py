@@ -104,9 +104,10 @@ for name, c in sq.items():
 # SQ_INSTS_VALU_* count wave-instructions; x 64 lanes / (12 * 2^20 lane-steps)
 top = {}
 for name, c in sq.items():
-    if not name.startswith("k_steps_chunks") or not name.endswith(", true>"):
+    # k_steps_chunks<S, T, VARIANT, ZV = true, REGBK = false>: the large-batch instantiations for zero end velocities
+    if not name.startswith("k_steps_chunks") or not name.endswith(", true, false>"):
         continue
-    lane_steps = float(PROBE_STEPS_F4 if ", 4, true>" in name else PROBE_STEPS) * N
+    lane_steps = float(PROBE_STEPS_F4 if ", 4, true, false>" in name else PROBE_STEPS) * N
     f64 = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0)
                   + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) / lane_steps
     f32 = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F32", 0) + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_ADD_F32", 0)
