@@ -1299,7 +1299,12 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
 #endif
     if (k >= chunks_from && k >= 1 && !grid_env) {
         // F3 below three waves per SIMD (3 x 1,024 SIMDs x 64 lanes): the instantiation whose step keeps its start in registers
-        if (b.variant == 3 && b.n <= (size_t)3 * 1024 * 64) {
+#ifdef RP_TUNING
+        static const size_t reg_column_upto = getenv("RP_REG_COLUMN_UPTO") ? (size_t)atol(getenv("RP_REG_COLUMN_UPTO")) : (size_t)3 * 1024 * 64;      // A/B: where the register column ends
+#else
+        constexpr size_t reg_column_upto = (size_t)3 * 1024 * 64;
+#endif
+        if (b.variant == 3 && b.n <= reg_column_upto) {
             constexpr int V3 = 3;
             if (b.zero_end_vel) { constexpr bool Z = true;  RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3))); }
             else                { constexpr bool Z = false; RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3))); }
