@@ -52,8 +52,11 @@ B_MOVED_F4_F32_ZV = 68.0
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_PEAK_TFLOPS = 78.6   # fp64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 FP32_PEAK_TFLOPS = 157.3  # fp32 vector peak, same guide
-PROFILE_TAG = "r4"        # profiles/<tag>_*.json hold the rocprofv3 counter summaries the file-sourced numbers come from
-KERNEL_SOURCES = ("rocket_path_amd/csrc/ip_core.h", "rocket_path_amd/csrc/ip_kernels.hip", "rocket_path_amd/csrc/feas_core.h")
+PROFILE_TAG = "r5"        # profiles/<tag>_*.json hold the rocprofv3 counter summaries the file-sourced numbers come from
+# everything that decides what a launch executes and moves: the per-lane code, the kernels, the launch selection (rp_batch.cpp: field
+# stride, which kernel a pass runs) and the scheduling pass (chunk order -> idle lane-steps, bytes per launch)
+KERNEL_SOURCES = ("rocket_path_amd/csrc/ip_core.h", "rocket_path_amd/csrc/ip_kernels.hip", "rocket_path_amd/csrc/feas_core.h",
+                  "rocket_path_amd/csrc/ip_kernels.h", "rocket_path_amd/csrc/rp_batch.cpp", "rocket_path_amd/csrc/schedule.hip")
 
 
 def source_hashes():
@@ -176,10 +179,27 @@ def free_port():
         return sk.getsockname()[1]
 
 
-def launch_ranks(n):
+def visible_devices():
+    """HIP devices a FRESH child process sees (this process must not touch HIP before it starts the ranks)."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import rocket_path_amd as rp; print(rp.device_count())" % ROOT],
+                       capture_output=True, text=True)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def launch_ranks(n, rehearsal=False):
     """`python bench.py --gpus N` as typed: this process has not imported torch nor touched HIP; it starts the N ranks as a
     child (torch.distributed.run, one process per GPU), relays what they print and returns their exit code."""
     import subprocess
+    if not rehearsal:
+        have = visible_devices()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d needs %d HIP devices, this machine shows %d (checked in a fresh child process): no ranks started. "
+                             "One process per GPU is the only form measured; --rehearse-on-one-gpu is the debug form.\n" % (n, n, have))
+            return 3
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RP_BENCH_SELF_LAUNCHED="1")
@@ -205,10 +225,13 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: run the N-rank code path with every rank on device 0 and gloo for the collectives "
                          "(RCCL refuses two ranks on one GPU); numbers from such a run are not benchmark results")
+    ap.add_argument("--sustain-seconds", type=float, default=0.0,
+                    help="extra, after the timed region: keep solving batches back to back for at least this many seconds and report the "
+                         "steady-state rate with clock / power samples (rocm-smi) -- the thermal-steady figure the 4 ms timed region cannot show")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus))
+        raise SystemExit(launch_ranks(args.gpus, rehearsal=args.rehearse_on_one_gpu))
 
     import torch
     import torch.distributed as dist
@@ -280,6 +303,8 @@ def main():
     barrier()
 
     # ---- timed: exactly K passes, then the final summary reduction (+ all-reduce) ----
+    # (the host clock is read at three more points inside the region, so that the line can say where an N-rank run's time went:
+    # this rank's launches + reduction done / the summary all-reduce returned / the closing barrier passed)
     t0 = time.perf_counter()
     lead.event_record(0)
     last = lead
@@ -291,9 +316,14 @@ def main():
     lead.event_record(1)
     last.reduce_device(summary.data_ptr())
     lead.sync()
+    t_kernels = time.perf_counter()
     summary = sharding.allreduce_summary(summary.to(coll_dev), force=grouped)
+    if grouped and not rehearsal:
+        torch.cuda.synchronize()         # the all-reduce is asynchronous on the device: its end, not its enqueue
+    t_coll = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    t_end = t0 + elapsed
 
     kernel_ms = lead.event_elapsed_ms(0, 1) / max(K, 1)
     sustained_ms = lead.event_elapsed_ms(6, 1) / (K - half) if 0 < half < K else kernel_ms
@@ -311,6 +341,17 @@ def main():
     else:
         steps_all, conv_all = steps_local, conv_local
     g = sharding.summary_dict(summary)
+    # per rank: launch time from its HIP events, the three host-clock pieces of the timed region, the device it really sat on
+    mine = [kernel_ms * K, sustained_ms, (t_kernels - t0) * 1e3, (t_coll - t_kernels) * 1e3, (t_end - t_coll) * 1e3, steps_local]
+    my_dev = rp.device_id(local_rank)
+    if grouped:
+        rows = [torch.zeros(len(mine), dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(rows, torch.tensor(mine, dtype=torch.float64, device=coll_dev))
+        per_rank = [[float(x) for x in r.tolist()] for r in rows]
+        devs = [None] * world
+        dist.all_gather_object(devs, my_dev)
+    else:
+        per_rank, devs = [mine], [my_dev]
 
     if rank != 0:
         if grouped:
@@ -350,6 +391,23 @@ def main():
         "steps": K,
         "warmup": W,
         "ms_per_step": elapsed / max(K, 1) * 1e3,
+        # where the timed region's wall clock went (max over ranks is what `value` divides by): every rank's K launches by its own HIP
+        # events, then three host-clock pieces -- launches + local reduction done, summary all-reduce done, closing barrier passed.  A
+        # rank that finishes early waits in the collective, so collective_ms_min is the collective's own latency and the spread of
+        # kernels_ms is the ranks' skew; `devices` must be N different GPUs for an N-GPU figure
+        "timed_region_breakdown": {
+            "region_ms": elapsed * 1e3,
+            "kernels_ms_per_rank": [r[0] for r in per_rank], "kernels_ms_min": min(r[0] for r in per_rank), "kernels_ms_max": max(r[0] for r in per_rank),
+            "sustained_ms_per_launch_per_rank": [r[1] for r in per_rank],
+            "host_until_local_work_done_ms_per_rank": [r[2] for r in per_rank],
+            "collective_ms_per_rank": [r[3] for r in per_rank], "collective_ms_min": min(r[3] for r in per_rank), "collective_ms_max": max(r[3] for r in per_rank),
+            "barrier_ms_per_rank": [r[4] for r in per_rank], "barrier_ms_max": max(r[4] for r in per_rank),
+            "note": "kernels: HIP events on the rank's stream around its K launches; the other pieces: that rank's host clock"},
+        "devices": devs,
+        "devices_distinct": len(set(devs)) == len(devs),
+        "devices_note": (None if len(set(devs)) == len(devs) else
+                         ("REHEARSAL: every rank on one GPU -- not an N-GPU measurement" if rehearsal else "RANKS SHARE A GPU: not an N-GPU measurement")),
+        "per_gpu_newton_steps_per_s": [r[5] / (r[0] * 1e-3) if r[0] > 0 else None for r in per_rank],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -401,6 +459,71 @@ def main():
             },
         },
     }
+
+    # ---- opt-in: the steady state (--sustain-seconds S).  The timed region above is ~4 ms, half of it before the power controller has
+    # reacted; here the pool's batches are solved back to back for at least S seconds (per round: every batch put back on its start,
+    # untimed by the events, then every batch solved, HIP-event timed), with rocm-smi sampled beside it ----
+    def sustain(seconds):
+        import csv
+        import io
+        import subprocess
+        import threading
+        samples, stop = [], [False]
+
+        def poll():
+            while not stop[0]:
+                try:
+                    out = subprocess.run(["rocm-smi", "-d", str(local_rank), "--showpower", "--showclocks", "--showtemp", "--csv"],
+                                         capture_output=True, text=True, timeout=5).stdout
+                    rows = list(csv.reader(io.StringIO(out.strip())))
+                    if len(rows) >= 2:
+                        samples.append((time.perf_counter(), dict(zip(rows[0], rows[-1]))))
+                except Exception as exc:      # an extra: never takes the benchmark down
+                    samples.append((time.perf_counter(), {"error": str(exc)}))
+                time.sleep(0.1)
+        th = threading.Thread(target=poll, daemon=True)
+        th.start()
+        time.sleep(0.3)                        # a few idle samples first
+        rounds = []
+        lead.sync()
+        t_start = time.perf_counter()
+        while True:
+            for b in batches:
+                b.restart()
+            lead.event_record(2)
+            for b in batches:
+                b.solve(GAP_TOL, MAX_ITER, 0)
+            lead.event_record(3)
+            lead.sync()
+            now = time.perf_counter()
+            rounds.append((now - t_start, lead.event_elapsed_ms(2, 3) / len(batches)))
+            if now - t_start >= seconds:
+                break
+        t_stop = time.perf_counter()
+        time.sleep(0.3)
+        stop[0] = True
+        th.join()
+        spl = steps_local / max(K, 1)
+        late = [ms for t, ms in rounds if t >= 0.5 * rounds[-1][0]] or [rounds[-1][1]]
+
+        def numeric(window):
+            cols = {}
+            for _, d in window:
+                for k, v in d.items():
+                    try:
+                        cols.setdefault(k, []).append(float(str(v).strip("()MHzWCmVc% ")))
+                    except ValueError:
+                        pass
+            return {k: {"min": min(v), "median": float(np.median(v)), "max": max(v)} for k, v in cols.items() if k.lower() != "device"}
+        under = [x for x in samples if t_start + 0.5 * (t_stop - t_start) <= x[0] <= t_stop]
+        idle = [x for x in samples if x[0] < t_start]
+        return {"seconds": t_stop - t_start, "rounds": len(rounds), "batches_per_round": len(batches),
+                "ms_per_launch_first_round": rounds[0][1], "ms_per_launch_second_half": float(np.mean(late)),
+                "steady_newton_steps_per_s": spl / (float(np.mean(late)) * 1e-3),
+                "wall_clock_newton_steps_per_s_including_the_restarts": spl * len(batches) * len(rounds) / (t_stop - t_start),
+                "rocm_smi_idle_before": numeric(idle), "rocm_smi_second_half_under_load": numeric(under), "rocm_smi_samples": len(samples),
+                "note": "per round every pool batch is put back on its feasible start (k_restart_feasible, outside the events) and then solved "
+                        "(k_solve_chunks, HIP events around the solves only); the GPU runs the fp64 solve ~90 % of the window"}
 
     # ---- end to end: bare positions -> solutions, per fresh batch (nothing precomputed), HIP-event timed ----
     def end_to_end(reps):
@@ -596,10 +719,43 @@ def main():
                 c2.event_record(5)
                 c2.sync()
                 ms.append(c2.event_elapsed_ms(4, 5))
+        # ... and a gated solve of the same 65,536 problems beside it (the form a caller who wants solutions would run)
+        with rp.Batch(n2, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) as c2g:
+            msg = []
+            for _ in range(4):
+                c2g.set_problems_device(*ptrs)
+                c2g.restart()
+                c2g.sync()
+                c2g.event_record(4)
+                c2g.solve(GAP_TOL, MAX_ITER, 0)
+                c2g.event_record(5)
+                c2g.sync()
+                msg.append(c2g.event_elapsed_ms(4, 5))
+            gated_steps = c2g.reduce()["total_steps"]
+        t50 = min(ms[1:])
+        f50_flop, f50_src = profile_number(PROFILE_TAG + "_sq_counters.json", "_flop_per_fixed50_launch")
+        f50_insts, _ = profile_number(PROFILE_TAG + "_sq_counters.json", "_valu_wave_insts_per_fixed50_launch")
+        f50_all, _ = profile_number(PROFILE_TAG + "_sq_counters.json", "_wave_insts_per_fixed50_launch")
+        f50_roof = None
+        if f50_flop is not None and fresh and n2 == 65536:
+            tf = f50_flop / (t50 * 1e-3) / 1e12
+            f50_roof = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                        "flop_per_launch": f50_flop, "source": f50_src,
+                        "valu_issue": None if f50_insts is None else {
+                            "achieved": f50_insts / (t50 * 1e-3) / 1e9, "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instructions/s",
+                            "frac": f50_insts / (t50 * 1e-3) / 1e9 / VALU_ISSUE_PEAK_G, "valu_wave_instructions_per_launch": f50_insts,
+                            "all_wave_instructions_per_launch": f50_all},
+                        "note": "65,536 problems are 1,024 waves: ONE wave per SIMD, and a lone wave issues one instruction of ANY kind (vector, scalar, "
+                                "branch) per ~2.3 ns plus its dependency stalls (SQ counters: 74 % of the wave's cycles issuing, 25 % parked) -- the "
+                                "launch is bound by the LENGTH of one wave's instruction stream (~1,900 instructions per post-convergence step), not by "
+                                "the chip's arithmetic; profiles/r5_tuning.md has the batch-size grid that rules out part-filled waves and "
+                                "several-lanes-per-problem forms at this size"}
         line["fixed50"] = {"workload": "BASELINE configs[1] (C2): 65,536 problems x exactly 50 steps, one fused launch "
                                        "(about 35 of the 50 steps per problem run in the reference's post-convergence regime: "
                                        "~48 residual halvings per step)",
-                           "ms": min(ms[1:]), "newton_steps_per_s": n2 * 50 / (min(ms[1:]) * 1e-3)}
+                           "ms": t50, "newton_steps_per_s": n2 * 50 / (t50 * 1e-3), "roofline": f50_roof,
+                           "gated_solve_of_the_same_problems": {"ms": min(msg[1:]), "newton_steps": gated_steps,
+                                                                "newton_steps_per_s": gated_steps / (min(msg[1:]) * 1e-3)}}
         # (c) configs[4]: F4, 1,048,576 problems x 50 steps from the feasible start, fp32 state (76 B algorithmic per step), in
         #     both arithmetic modes: fp32 state + fp64 arithmetic (per-problem parity bound, tests/test_gpu_parity.py) and
         #     pure fp32 arithmetic (statistical bound only)
@@ -711,6 +867,9 @@ def main():
                                  "roofline": feas_roofline(t_f, n7),
                                  "note": "16 fields read, 3 written per problem; the arithmetic (Gram matrix, Eigen-ordered 4 x 4 column-pivoted "
                                          "Householder QR in double precision, one problem per lane) is what the launch time is made of"}}
+
+    if args.sustain_seconds > 0:
+        line["sustained"] = sustain(args.sustain_seconds)
 
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(count, 1 << 19))

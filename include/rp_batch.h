@@ -45,8 +45,9 @@ typedef struct rp_batch rp_batch; /* opaque, owned by the caller between create 
  *   1  round 1      2  round 2: rp_params + mu_mode / mu_sigma_try; rp_batch_field_ptr returns batch order (rp_batch_slot_map)
  *   3  round 3: sizeof(rp_params) returned by rp_params_size(); set_problems defers the feasible start
  *   4  round 4: rp_solution records (rp_batch_solution_device, rp_batch_bind_solution); rp_batch_traffic_probe replaces an
- *      environment switch; the library reads nothing from the environment; rp_batch_sample_device checks its alignment */
-#define RP_ABI_VERSION 4
+ *      environment switch; the library reads nothing from the environment; rp_batch_sample_device checks its alignment
+ *   5  round 5: rp_device_id; a bound solution buffer is seeded before a gated launch that skips finished problems */
+#define RP_ABI_VERSION 5
 
 typedef enum {
     RP_OK = 0,
@@ -122,6 +123,9 @@ RP_API size_t rp_params_size(void);    /* sizeof(rp_params) in the library: must
 RP_API const char *rp_last_error(void); /* thread-local text of the last failure */
 RP_API const char *rp_status_string(int status);
 RP_API int rp_device_count(int *count);
+/* "pci <domain:bus:device.function> uuid <hex>" of HIP device `device` into out (len >= 64).  New -- the reference is one process
+ * on no device; a multi-GPU host (bench.py, ShardedOneDPathIP) reports with it that its N shards really sat on N different GPUs. */
+RP_API int rp_device_id(int device, char *out, size_t len);
 RP_API void rp_params_default(rp_params *p);
 
 /* ---- lifetime ---- */
@@ -196,9 +200,13 @@ RP_API int rp_batch_get_iters(rp_batch *b, int32_t *iters, uint32_t *status); /*
 RP_API int rp_batch_solution_device(rp_batch *b, rp_solution *d_out);
 /* Bind (NULL: unbind) a buffer of n records: from now on every gated solve (rp_batch_solve, rp_batch_solve_launch) writes the
  * record of each problem it works on as that problem leaves the launch -- "positions in, solutions out in problem order" then
- * costs no extra pass (the one 32-byte sector per problem is written under the solve's arithmetic).  After a fused solve of a
- * batch every record is current; calls other than gated solves (rp_batch_step, nudges, set_state ...) do not update the
- * buffer -- use rp_batch_solution_device for the state they leave.  The buffer must outlive the binding. */
+ * costs no extra pass (the one 32-byte sector per problem is written under the solve's arithmetic).  After a gated solve of a
+ * batch EVERY record is current, also those of problems that had finished in an earlier launch and that this one skipped: a
+ * launch that may skip problems is preceded by one pass that writes all records from the state as it is (k_solution, 68 B per
+ * problem) whenever the buffer is new or anything but gated solves has touched the state since the records were written; the
+ * first solve of a batch that has just been given its problems stores every record itself and needs no such pass.  Calls other
+ * than gated solves (rp_batch_step, nudges, set_state ...) do not update the buffer -- use rp_batch_solution_device for the
+ * state they leave.  The buffer must outlive the binding. */
 RP_API int rp_batch_bind_solution(rp_batch *b, rp_solution *d_out);
 RP_API int rp_batch_reduce(rp_batch *b, rp_reduction *out);                   /* synchronous */
 /* Writes the 4 doubles of rp_reduction to device memory the caller owns, asynchronously on
@@ -240,7 +248,10 @@ RP_API int rp_batch_event_elapsed_ms(rp_batch *b, int slot_start, int slot_stop,
  * element is ptr[slot_of_problem[i]] with the map of rp_batch_slot_map.  Asking for an end-velocity field
  * (vel0X / vel2X) makes the batch assume they may become non-zero (general kernels) until the next init /
  * set_problems / set_state.  A pointer taken earlier is undefined between rp_batch_set_problems(_device) and the next call
- * that touches the state (the feasible start is written lazily): take it again after set_problems. */
+ * that touches the state (the feasible start is written lazily): take it again after set_problems.  Once a pointer to a
+ * CONSTANT field (positions, end velocities) has been handed out the batch assumes for the rest of its life that positions may be
+ * written behind its back: rp_batch_sample_device then always reads them from the fields (the gather path), never from the
+ * records set_problems kept. */
 RP_API int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr);
 /* slot_of_problem[i] = position of problem i inside the batch's field arrays (n words; the identity after
  * init_default / init_stuck).  Every other entry point takes and returns problem order; only rp_batch_field_ptr

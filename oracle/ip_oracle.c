@@ -602,6 +602,110 @@ static void step_with(int variant, double *var, double *d, orc_step_info *info, 
     }
 }
 
+/* The residual test of the reference's second backtracking loop (`if (rn <= r0 * (1 - 0.01 * s)) break;`, onedpath_ip.cpp:941,
+ * onedpath2_ip.cpp:828) laid open at ONE trial.  From the state `var` a step starts from: the direction, the boundary fraction and
+ * the feasibility loop exactly as in step_with, then the trial the residual loop makes after `halvings` halvings of its own
+ * (whatever the trials before it decided): out[0] = |r(x + s d)|^2, out[1] = |r(x)|^2 (1 - 0.01 s), out[2] = s, out[3] = the
+ * largest change of out[0] when ONE of the 3 + m coordinates of that trial point moves by one unit in the last place (either way).
+ * Returns 0 when the loop's budget ends before that trial.  Test infrastructure: it lets the GPU tests CERTIFY that a device
+ * decision which differs from the oracle's was made within rounding of the threshold, instead of budgeting such differences. */
+int orc_armijo_sides(int variant, const double *var, int halvings, orc_qr_solver solver, double out[4])
+{
+    const int m = orc_num_constraints(variant);
+    const int c = NV + m;
+    double mat[MAXN * MAXN], r[MAXN], neg_r[MAXN], d[MAXN], trial[ORC3_M], moved[ORC3_M];
+    double perturbation, s, r0, rn, spread = 0.0;
+    int i, sign;
+
+    orc_kkt(variant, var, mat, r, &perturbation);
+    for (i = 0; i < c; ++i) neg_r[i] = -r[i];
+    if (solver) solver(c, mat, neg_r, d, 0);
+    else orc_colpiv_qr_solve(c, mat, neg_r, d);
+    s = 1.0;
+    for (i = 0; i < m; ++i) {
+        const double dLm = d[NV + i];
+        if (dLm < 0.0) {
+            const double q = -var[NV + i] / dLm;
+            if (q < s) s = q;
+        }
+    }
+    s *= 0.99;
+    for (i = 0; i < 100; ++i) {
+        trajectory_step(variant, var, d, s, trial);
+        if (orc_constraints_satisfied(variant, trial)) break;
+        s *= 0.5;
+    }
+    if (halvings < 0 || halvings >= 100) return 0;
+    for (i = 0; i < halvings; ++i) s *= 0.5;
+    r0 = orc_residual_norm(variant, var, perturbation);
+    trajectory_step(variant, var, d, s, trial);
+    rn = orc_residual_norm(variant, trial, perturbation);
+    for (i = 0; i < c; ++i)
+        for (sign = -1; sign <= 1; sign += 2) {
+            double rm, dlt;
+            memcpy(moved, trial, sizeof(double) * (size_t)orc_state_len(variant));
+            moved[i] = nextafter(trial[i], sign < 0 ? -HUGE_VAL : HUGE_VAL);
+            rm = orc_residual_norm(variant, moved, perturbation);
+            dlt = fabs(rm - rn);
+            if (dlt > spread) spread = dlt;
+        }
+    out[0] = rn;
+    out[1] = r0 * (1.0 - 0.01 * s);
+    out[2] = s;
+    out[3] = spread;
+    return 1;
+}
+
+/* The feasibility test of the first backtracking loop (`if (constraintsSatisfied(trial)) break;`, onedpath_ip.cpp:919-928,
+ * onedpath2_ip.cpp:791-800) laid open at the trial made after `halvings` halvings: out[0] = the largest constraint value at that
+ * trial (> 0: rejected), out[1] = s, out[2] = the largest change of any constraint value when one of the three variables of that
+ * trial point moves by one unit in the last place.  Same purpose as orc_armijo_sides. */
+int orc_feasibility_margin(int variant, const double *var, int halvings, orc_qr_solver solver, double out[3])
+{
+    const int m = orc_num_constraints(variant);
+    const int c = NV + m;
+    double mat[MAXN * MAXN], r[MAXN], neg_r[MAXN], d[MAXN], trial[ORC3_M], moved[ORC3_M], err0[8];
+    double perturbation, s, worst = -HUGE_VAL, spread = 0.0;
+    int i, j, sign;
+
+    orc_kkt(variant, var, mat, r, &perturbation);
+    for (i = 0; i < c; ++i) neg_r[i] = -r[i];
+    if (solver) solver(c, mat, neg_r, d, 0);
+    else orc_colpiv_qr_solve(c, mat, neg_r, d);
+    s = 1.0;
+    for (i = 0; i < m; ++i) {
+        const double dLm = d[NV + i];
+        if (dLm < 0.0) {
+            const double q = -var[NV + i] / dLm;
+            if (q < s) s = q;
+        }
+    }
+    s *= 0.99;
+    if (halvings < 0 || halvings >= 100) return 0;
+    for (i = 0; i < halvings; ++i) s *= 0.5;
+    trajectory_step(variant, var, d, s, trial);
+    for (i = 0; i < m; ++i) {
+        double grad[3];
+        orc_constraint(variant, i, trial, &err0[i], grad);
+        if (err0[i] > worst) worst = err0[i];
+    }
+    for (j = 0; j < NV; ++j)
+        for (sign = -1; sign <= 1; sign += 2) {
+            memcpy(moved, trial, sizeof(double) * (size_t)orc_state_len(variant));
+            moved[j] = nextafter(trial[j], sign < 0 ? -HUGE_VAL : HUGE_VAL);
+            for (i = 0; i < m; ++i) {
+                double e, grad[3], dlt;
+                orc_constraint(variant, i, moved, &e, grad);
+                dlt = fabs(e - err0[i]);
+                if (dlt > spread) spread = dlt;
+            }
+        }
+    out[0] = worst;
+    out[1] = s;
+    out[2] = spread;
+    return 1;
+}
+
 void orc_step_dir(int variant, double *var, double *d, orc_step_info *info)
 {
     orc_step_ex(variant, var, d, info, NULL);

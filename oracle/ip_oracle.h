@@ -19,13 +19,14 @@
  *   QR  libs/eigen/Eigen/src/QR/ColPivHouseholderQR.h:480-611,
  *       libs/eigen/Eigen/src/Householder/Householder.h:65-131
  *
- * Parity pin: the reference TUs themselves cannot be compiled in this image without
- * writing a stand-in for <GL/glu.h>/<GL/glut.h>, so they count as unbuildable.  The
- * restatement is pinned by (1) the known-answer vectors the survey captured from the
- * unmodified reference (committed as tests/golden/survey_kat.json)
- * and (2) the reference's vendored Eigen 3.3.0 ColPivHouseholderQR compiled from where
- * it lies into oracle/_ref/ and compared with orc_colpiv_qr_solve on the KKT systems the
- * step produces.  See DESIGN.md "Oracle".
+ * Parity pin (pinned): the reference's own hot-path functions, compiled in the build container from the
+ * files where they lie -- `make -C oracle ref` pipes the GL-free line ranges of onedpath_ip.cpp /
+ * onedpath2_ip.cpp into the compiler (real headers, the vendored Eigen 3.3.0, nothing stood in for;
+ * ref_build/ref_hotpath.cpp) -> oracle/_ref/libref_hotpath.so.  tests/test_oracle_reference.py holds
+ * this restatement to it BIT FOR BIT (model functions, moveInteriorPoint with the reference's Eigen QR
+ * doing the solve, gated solves, moveTowardFeasibility, every committed fixture); the survey's
+ * known-answer vectors (tests/golden/survey_kat.json) are a second, independent record
+ * of the same outputs.  See DESIGN.md "Oracle".
  *
  * Build: plain C99, no FMA contraction (-ffp-contract=off, no -march flags), so the
  * arithmetic is the reference's x86-64 SSE2 arithmetic operation for operation.
@@ -100,6 +101,13 @@ void   orc_step_ex(int variant, double *var, double *d, orc_step_info *info, orc
 void   orc_step_params(int variant, double *var, orc_step_info *info, double backtrack, int max_bt);
 void   orc_batch_steps_params(int variant, size_t n, double *aos, int k, int threads, double backtrack, int max_bt);
 void   orc_move_toward_feasibility(int variant, double *var);
+/* the residual test of the second backtracking loop (onedpath_ip.cpp:941 / onedpath2_ip.cpp:828) laid open at the trial made after
+   `halvings` halvings: out = { |r(trial)|^2, |r(x)|^2 (1 - 0.01 s), s, largest change of out[0] under a one-ulp move of one trial
+   coordinate }; 0 if the loop's budget ends before that trial.  For certifying decisions that differ by a rounding. */
+int    orc_armijo_sides(int variant, const double *var, int halvings, orc_qr_solver solver, double out[4]);
+/* the feasibility test of the first backtracking loop (onedpath_ip.cpp:919-928) at the trial made after `halvings` halvings:
+   out = { largest constraint value there (> 0: rejected), s, largest change of a constraint value under a one-ulp move of one variable } */
+int    orc_feasibility_margin(int variant, const double *var, int halvings, orc_qr_solver solver, double out[3]);
 
 void   orc_init_default(int variant, double *var);
 void   orc_init_stuck_f3(double *var);

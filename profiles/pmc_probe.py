@@ -6,7 +6,8 @@ known number of steps at 1 Mi problems:
     F4 f32          50 fused ungated steps   -> k_steps_chunks<float, float, 4, true>     (BASELINE configs[4] itself: F4's line search
     F4 f32 state    50 fused ungated steps   -> k_steps_chunks<float, double, 4, true>     only sets in from step ~6, so 12 steps undercount)
 then the gated kernel (k_solve_chunks) on 524,288 identical default problems (15 steps each: its instructions per step without idle lanes),
-the benchmark's gated solve (occupancy / busy counters of the real launch), one k = 1 launch, and the feasibility move
+the benchmark's gated solve (occupancy / busy counters of the real launch), one k = 1 launch, BASELINE configs[1] (65,536 x 50 fixed steps,
+and 15 steps of 65,472 problems beside it), and the feasibility move
 (k_move_toward_feasibility) on 1 Mi starts with four violated rows each -- bench.py's `neighbours.feasibility_move` workload."""
 import os
 import sys
@@ -44,6 +45,17 @@ with rp.Batch(N) as b:
     b.restart()      # the feasible start written out (set_problems defers it to a fused solve)
     b.step(1)
     b.sync()
+# BASELINE configs[1]: 65,536 problems x 50 fixed steps (one wave per SIMD; k_steps_chunks<double, double, 3, true, true>, the register-column
+# instantiation), and the first 15 steps of a batch one chunk smaller (65,472 problems: told apart by its grid size) -- the difference is
+# the post-convergence regime's share
+for nn, kk in ((65536, 50), (65536 - 64, 15)):
+    q0, q1, q2 = rp.problems.generate(12345, 0, nn, 0)
+    with rp.Batch(nn) as b:
+        for _ in range(2):
+            b.set_problems(q0, q1, q2)
+            b.restart()
+            b.step(kk)
+            b.sync()
 # the feasibility move on 1 Mi starts pushed out of the feasible set (both durations too short: four violated rows each)
 with rp.Batch(N) as b:
     b.set_problems(p0, p1, p2)

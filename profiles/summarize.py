@@ -142,6 +142,40 @@ for name, c in sq.items():      # the feasibility move: one launch over 1 Mi sta
         if "SQ_INSTS_VALU" in c:
             c["valu_insts_per_problem"] = 64.0 * c["SQ_INSTS_VALU"] / N
             top["_valu_insts_per_feasibility_move_4_rows"] = c["valu_insts_per_problem"]
+# BASELINE configs[1] (pmc_probe.py): 65,536 problems x 50 steps = grid 65,536 of the register-column chunk kernel; its first 15 steps on
+# 65,472 problems = grid 65,472.  Per launch (not per lane-step: the post-convergence steps are nothing like the first fifteen).
+SMALL = "k_steps_chunks<double, double, 3, true, true>"
+f50, f15 = {}, {}
+for d in sq_dirs:
+    for k, cs in counters(d, grid=65536).items():
+        if short(k) == SMALL:
+            f50.update(cs)
+    for k, cs in counters(d, grid=65536 - 64).items():
+        if short(k) == SMALL:
+            f15.update(cs)
+
+
+def launch_flop(c):
+    return 64.0 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_TRANS_F64"])
+
+
+if "SQ_INSTS_VALU_FMA_F64" in f50 and "SQ_INSTS_VALU" in f50:
+    sq[SMALL + " configs[1]: 65,536 x 50"] = f50
+    top["_flop_per_fixed50_launch"] = launch_flop(f50)
+    top["_valu_wave_insts_per_fixed50_launch"] = f50["SQ_INSTS_VALU"]
+    top["_wave_insts_per_fixed50_launch"] = f50["SQ_INSTS_VALU"] + f50.get("SQ_INSTS_SALU", 0.0)
+    if "SQ_INSTS_VALU" in f15 and "SQ_WAVES" in f15:
+        sq[SMALL + " 65,472 x 15"] = f15
+        w50, w15 = f50["SQ_WAVES"], f15["SQ_WAVES"]
+        per = lambda key: ((f50[key] / w50 - f15[key] / w15) / 35.0, f15[key] / w15 / 15.0)      # noqa: E731
+        split = {}
+        for key, label in (("SQ_INSTS_VALU", "valu"), ("SQ_INSTS_SALU", "salu"), ("SQ_WAVE_CYCLES", "wave_quad_cycles"), ("SQ_ACTIVE_INST_ANY", "issuing_quad_cycles"),
+                           ("SQ_WAIT_ANY", "parked_quad_cycles"), ("SQ_WAIT_INST_ANY", "stalled_quad_cycles")):
+            if key in f50 and key in f15:
+                late, early = per(key)
+                split[label + "_per_wave_step_steps_16_to_50"] = late
+                split[label + "_per_wave_step_steps_1_to_15"] = early
+        sq["_fixed50_per_wave_step"] = split
 sq.update(top)
 json.dump({"_method": "rocprofv3 --pmc <SQ counters, <= 8 per pass> -- python3 profiles/pmc_probe.py (1 Mi problems: 12 fused ungated steps "
                       "of F3 f64, 50 of F4 f32 / F4 f32-state, then the fused gated F3 solve and one k = 1 launch); SQ_WAVE_CYCLES / "
@@ -156,7 +190,8 @@ print(json.dumps(top, indent=1))
 import hashlib  # noqa: E402
 import subprocess  # noqa: E402
 
-KERNEL_SOURCES = ("rocket_path_amd/csrc/ip_core.h", "rocket_path_amd/csrc/ip_kernels.hip", "rocket_path_amd/csrc/feas_core.h")
+KERNEL_SOURCES = ("rocket_path_amd/csrc/ip_core.h", "rocket_path_amd/csrc/ip_kernels.hip", "rocket_path_amd/csrc/feas_core.h",
+                  "rocket_path_amd/csrc/ip_kernels.h", "rocket_path_amd/csrc/rp_batch.cpp", "rocket_path_amd/csrc/schedule.hip")      # = bench.py's list
 box_hashes = {}      # sha256sum output the collection script wrote next to the counter directories, on the box that ran the kernels
 try:
     for line in open(os.path.join(os.path.dirname(os.path.normpath(sq_dirs[0])), "sources.sha256")):
@@ -167,14 +202,22 @@ try:
         box_hashes = {}
 except Exception:
     box_hashes = {}
-try:
-    commit = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
-    dirty = bool(subprocess.run(["git", "status", "--porcelain", "--"] + list(KERNEL_SOURCES), cwd=ROOT, capture_output=True, text=True).stdout.strip())
-except Exception:
-    commit, dirty = None, None
+# The commit the kernel sources belong to: taken in the build container BEFORE the collection is sent to the GPU box (which has no .git)
+# and handed in through the environment by the collection script (profiles/collect_r5.sh: RP_COLLECT_COMMIT / RP_COLLECT_DIRTY); where the
+# summaries are folded inside a checkout, from git itself.
+commit, dirty = os.environ.get("RP_COLLECT_COMMIT") or None, os.environ.get("RP_COLLECT_DIRTY")
+commit_from = "RP_COLLECT_COMMIT: `git rev-parse HEAD` in the build container before the collection ran" if commit else None
+dirty = None if dirty is None else dirty not in ("", "0", "false")
+if commit is None:
+    try:
+        commit = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
+        dirty = bool(subprocess.run(["git", "status", "--porcelain", "--"] + list(KERNEL_SOURCES), cwd=ROOT, capture_output=True, text=True).stdout.strip())
+        commit_from = "git, where the summaries were folded" if commit else None
+    except Exception:
+        commit, dirty = None, None
 json.dump({"_what": "kernel sources the %s_* counter summaries were collected from (the .so that ran on the GPU box was built from these files); "
                     "bench.py compares the hashes with the files it finds" % tag,
-           "commit": commit, "kernel_sources_uncommitted_at_collection": dirty,
+           "commit": commit, "commit_from": commit_from, "kernel_sources_uncommitted_at_collection": dirty,
            "sha256_16": box_hashes or {f: hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest()[:16] for f in KERNEL_SOURCES},
            "hashes_taken": "on the GPU box by the collection script" if box_hashes else "where the summaries were folded (no sources.sha256 in the collection)"},
           open(os.path.join(ROOT, "profiles", "%s_sources.json" % tag), "w"), indent=1)

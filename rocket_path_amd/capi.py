@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librp_batch.so")
 
 RP_OK = 0
-ABI_VERSION = 4      # RP_ABI_VERSION of include/rp_batch.h this binding was written against
+ABI_VERSION = 5      # RP_ABI_VERSION of include/rp_batch.h this binding was written against
 RP_ERR_INVALID, RP_ERR_DEVICE, RP_ERR_NOMEM, RP_ERR_UNSUPPORTED, RP_ERR_NO_DEVICE = 1, 2, 3, 4, 5
 VARIANT_F3, VARIANT_F4 = 3, 4
 DTYPE_F64, DTYPE_F32, DTYPE_F32_STATE = 0, 1, 2      # 2: fp32 state in HBM, fp64 arithmetic (include/rp_batch.h)
@@ -57,6 +57,7 @@ SIGNATURES = {
     "rp_last_error": (ctypes.c_char_p, []),
     "rp_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "rp_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "rp_device_id": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]),
     "rp_params_default": (None, [ctypes.POINTER(Params)]),
     "rp_batch_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, _vp]),
     "rp_batch_destroy": (ctypes.c_int, [_vp]),
@@ -139,3 +140,10 @@ def device_count():
     n = ctypes.c_int(0)
     load_library().rp_device_count(ctypes.byref(n))
     return n.value
+
+
+def device_id(device):
+    """'pci <bus id> uuid <hex>' of HIP device `device` (rp_device_id)."""
+    buf = ctypes.create_string_buffer(128)
+    check(load_library().rp_device_id(int(device), buf, 128))
+    return buf.value.decode()

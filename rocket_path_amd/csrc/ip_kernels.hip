@@ -470,7 +470,10 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
 // late in round 2 this was a 512-problem tile staged in LDS, the only form that fitted three waves per SIMD: the compiler
 // kept the eleven store addresses in registers across the steps.  Forming them after the steps, below, saved 16 VGPRs and
 // made the direct form both fit and win: 57.5 -> 65.5 G steps/s at k = 12.)
-template <int VARIANT, bool REGBK> constexpr int kStepsChunkWaves = (kStepInPlace<VARIANT, false, 0, NoDiag> && !REGBK) ? RP_GATED_WAVES : RP_TILED_WAVES;
+#ifndef RP_SMALL_WAVES
+#define RP_SMALL_WAVES RP_TILED_WAVES     // the register-column instantiation (batches that leave SIMDs with a lone wave): A/B knob, profiles/r5_tuning.md
+#endif
+template <int VARIANT, bool REGBK> constexpr int kStepsChunkWaves = (kStepInPlace<VARIANT, false, 0, NoDiag> && !REGBK) ? RP_GATED_WAVES : (REGBK ? RP_SMALL_WAVES : RP_TILED_WAVES);
 
 // REGBK (F3): the in-place step's start waits in registers instead of LDS, three waves per SIMD -- the instantiation for batches
 // that cannot fill three waves per SIMD anyway (launch_steps picks it below 196,608 problems): a lone wave has nothing to run
@@ -478,7 +481,7 @@ template <int VARIANT, bool REGBK> constexpr int kStepsChunkWaves = (kStepInPlac
 // makes one per halving.  Same arithmetic, same bits.
 template <typename S, typename T, int VARIANT, bool ZV, bool REGBK = false>
 __global__ void __launch_bounds__(64, (kStepsChunkWaves<VARIANT, REGBK>))
-k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp)
+k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, unsigned lanes)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;
@@ -487,8 +490,10 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     constexpr bool kInPlace = kStepInPlace<VARIANT, false, 0, NoDiag>;
     static_assert(kInPlace || !REGBK, "the register column belongs to the in-place step");
     __shared__ T s_backup[(kInPlace && !REGBK) ? (3 + NC + 2) * 64 : 1];
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
+    // lanes: problems per wave -- 64 in every shipped launch; tuning builds can leave the upper lanes of every wave empty
+    // (RP_LANES_PER_WAVE: part-filled waves for batches that cannot fill the chip, measured and not kept: profiles/r5_tuning.md)
+    const size_t i = (size_t)blockIdx.x * lanes + threadIdx.x;
+    if (threadIdx.x >= lanes || i >= n) return;
     S *f = base + i;
     T v = (T)ld_once(f + 0 * stride), t0 = (T)ld_once(f + 1 * stride), t1 = (T)ld_once(f + 2 * stride);
     T lam[NC];
@@ -532,7 +537,7 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     }
     // the store addresses are formed only now: the barrier keeps the compiler from holding eleven of them in registers
     // across the steps (168 VGPRs and 4-10 spilled without it, 152 with it)
-    size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
+    size_t j = (size_t)blockIdx.x * lanes + threadIdx.x;
     asm volatile("" : "+v"(j));
     S *g = base + j;
     st_once(g + 0 * stride, (S)v);
@@ -1306,12 +1311,18 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
 #endif
         if (b.variant == 3 && b.n <= reg_column_upto) {
             constexpr int V3 = 3;
-            if (b.zero_end_vel) { constexpr bool Z = true;  RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3))); }
-            else                { constexpr bool Z = false; RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3))); }
+#ifdef RP_TUNING
+            static const unsigned lanes = getenv("RP_LANES_PER_WAVE") ? (unsigned)atoi(getenv("RP_LANES_PER_WAVE")) : 64u;      // A/B: part-filled waves
+#else
+            constexpr unsigned lanes = 64u;
+#endif
+            const dim3 grid((unsigned)((b.n + lanes - 1) / lanes));
+            if (b.zero_end_vel) { constexpr bool Z = true;  RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), grid, dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3), lanes)); }
+            else                { constexpr bool Z = false; RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), grid, dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3), lanes)); }
             return hipGetLastError();
         }
         RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V, Z>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
-                                             (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V)));
+                                             (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), 64u));
         return hipGetLastError();
     }
     // k = 1: memory-bound.  Full blocks of 256 lanes x 16 B go through k_newton_stream16; the ragged remainder (and, in a

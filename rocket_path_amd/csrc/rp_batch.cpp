@@ -34,6 +34,11 @@ struct rp_batch {
     rp::Solution *d_solscratch;   // lazily allocated n solution records: the plot data of a whole batch reads its state through them
     bool records_current;     // view.records hold the positions the batch's constant fields hold (set_problems; until a set_state, an init,
                               // a nudge of a position or a raw field pointer handed out)
+    bool raw_positions_out;   // a raw pointer to a CONSTANT field (a position, an end velocity) has been handed out (rp_batch_field_ptr): the caller may
+                              // write positions the records never see, at any later time -- the records path of rp_batch_sample_device stays off
+                              // for the life of the batch
+    bool sol_stale;           // a solution buffer is bound and something other than a gated solve has touched the state (or the buffer is new): the
+                              // records of problems the next gated launch does NOT work on are not current -- that launch seeds the buffer first
     bool at_start;            // set_problems has run and nothing else since: the batch holds its scheduled order and its positions; the
                               // feasible start itself (mutable fields, progress words) is NOT materialised yet -- see materialize()
     double ungated_steps;     // per-problem count of ungated steps since the last init
@@ -128,6 +133,19 @@ int materialize(rp_batch *b)
     return RP_OK;
 }
 
+// A gated launch writes the bound solution record of every problem it WORKS ON (k_solve_chunks); problems that finished in an
+// earlier launch are skipped without touching their state.  Their records are current only if nothing but gated solves has run
+// since they were written: otherwise (a new buffer, steps, a nudge, a set_state ... in between) the launch is preceded by one pass
+// that writes every record from the state as it is (k_solution, 68 B per problem).  Not on the fresh-batch path: a START launch
+// stores every record itself.
+int seed_solution(rp_batch *b)
+{
+    if (!b->view.solution || !b->sol_stale) return RP_OK;
+    RP_HIP(rp::launch_solution(b->view, b->view.solution, b->stream));
+    b->sol_stale = false;
+    return RP_OK;
+}
+
 #define RP_NEED_STATE(b)                     \
     do {                                     \
         RP_NEED(b);                          \
@@ -189,6 +207,26 @@ int rp_device_count(int *count)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return fail(RP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     *count = n;
+    return RP_OK;
+}
+
+int rp_device_id(int device, char *out, size_t len)
+{
+    if (!out || len < 64) return fail(RP_ERR_INVALID, "rp_device_id needs a buffer of at least 64 bytes");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); return fail(RP_ERR_NO_DEVICE, "no HIP device visible"); }
+    if (device < 0 || device >= n) return fail(RP_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+    char bus[32] = "";
+    RP_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof bus, device));
+    hipUUID uuid;
+    std::memset(&uuid, 0, sizeof uuid);
+    char hex[2 * sizeof uuid.bytes + 1] = "";
+    if (hipDeviceGetUuid(&uuid, device) == hipSuccess) {
+        for (size_t i = 0; i < sizeof uuid.bytes; ++i) snprintf(hex + 2 * i, 3, "%02x", (unsigned)(unsigned char)uuid.bytes[i]);
+    } else {
+        (void)hipGetLastError();
+    }
+    snprintf(out, len, "pci %s uuid %s", bus, hex[0] ? hex : "?");
     return RP_OK;
 }
 
@@ -370,6 +408,7 @@ int rp_batch_init_default(rp_batch *b)
     for (int i = 0; i < m; ++i) s[3 + i] = 1.0;
     s[3 + m + 0] = 0.0; s[3 + m + 1] = 0.0; s[3 + m + 2] = 200.0; s[3 + m + 3] = 400.0; s[3 + m + 4] = 0.0;
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
+    b->sol_stale = true;
     b->view.zero_end_vel = true;
     b->view.scheduled = false;         // identical problems: nothing to schedule
     b->at_start = false;
@@ -386,6 +425,7 @@ int rp_batch_init_stuck(rp_batch *b)
                           5.45948e-07, 0.00310769, 3.49109e-08, 0.00281523, 8.39344e-07, 1.76937e-06, 0.0187559, 8.42414e-07,
                           0.0, 0.0, 350.0, 400.0, 0.0};
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
+    b->sol_stale = true;
     b->view.zero_end_vel = true;
     b->view.scheduled = false;
     b->at_start = false;
@@ -409,6 +449,7 @@ int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double
     if (st != RP_OK) return st;
     b->view.zero_end_vel = true;       // the feasible-start rule sets vel0 = vel2 = 0
     b->ungated_steps = 0.0;
+    b->sol_stale = true;
     b->at_start = true;
     b->records_current = true;
     return RP_OK;
@@ -417,6 +458,7 @@ int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double
 int rp_batch_restart(rp_batch *b)
 {
     RP_NEED(b);
+    b->sol_stale = true;
     if (b->at_start) return materialize(b);      // already at the start of its positions: write it out
     RP_HIP(rp::launch_restart_feasible(b->view, b->params, b->stream));
     b->view.zero_end_vel = true;
@@ -460,6 +502,7 @@ int rp_batch_set_state(rp_batch *b, const double *aos)
         if (st != RP_OK) return st;
         b->at_start = false;      // the rows below are the state
         b->records_current = false;
+        b->sol_stale = true;
     }
     RP_HIP(rp::launch_aos_to_soa(b->view, b->d_aos, b->stream));
     st = reset_progress(b);
@@ -502,6 +545,7 @@ int rp_batch_nudge(rp_batch *b, int var_index, double delta)
     RP_NEED_STATE(b);
     if (var_index < 0 || var_index >= rp::state_len(b->view.variant)) return fail(RP_ERR_INVALID, "variable index %d out of range", var_index);
     RP_HIP(rp::launch_nudge(b->view, var_index, delta, b->stream));
+    b->sol_stale = true;
     if (var_index >= 3 + rp::num_constraints(b->view.variant)) b->records_current = false;      // a constant moved: the records no longer are the batch's positions
     {
         const int iv0 = 3 + rp::num_constraints(b->view.variant) + 1, iv2 = iv0 + 3;
@@ -517,6 +561,7 @@ int rp_batch_step(rp_batch *b, int k)
     if (k == 0) return RP_OK;
     RP_HIP(rp::launch_steps(b->view, b->params, k, b->stream));
     b->ungated_steps += (double)k;
+    b->sol_stale = true;
     return RP_OK;
 }
 
@@ -550,6 +595,7 @@ int rp_batch_step_counted(rp_batch *b, int k, uint32_t *feas_halvings, uint32_t 
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RP_ERR_DEVICE, "rp_batch_step_counted: %s", hipGetErrorString(e));
     b->ungated_steps += (double)k;
+    b->sol_stale = true;
     return RP_OK;
 }
 
@@ -564,11 +610,14 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
         if (from_start) b->at_start = false;
         else { const int ms = materialize(b); if (ms != RP_OK) return ms; }
         b->view.iters_add = (int)b->ungated_steps;
+        if (!from_start) { const int ss = seed_solution(b); if (ss != RP_OK) return ss; }      // (the START launch stores every record itself)
+        b->sol_stale = false;
         RP_HIP(rp::launch_solve_fused(b->view, b->params, gap_tol, max_iter, from_start, b->stream));
         return RP_OK;
     }
     { const int ms = materialize(b); if (ms != RP_OK) return ms; }
     b->view.iters_add = (int)b->ungated_steps;
+    { const int ss = seed_solution(b); if (ss != RP_OK) return ss; }
     // bounded host loop: every launch either finishes a problem or advances it by >= 1 step
     const int max_launches = max_iter / steps_per_launch + 2;
     for (int l = 0; l < max_launches; ++l) {
@@ -589,6 +638,7 @@ int rp_batch_solve_launch(rp_batch *b, double gap_tol, int max_iter, int k)
     if (k < 1 || k > 1000000) return fail(RP_ERR_INVALID, "steps per launch %d out of range (1..1000000)", k);
     if (!(gap_tol == gap_tol)) return fail(RP_ERR_INVALID, "gap_tol is NaN");
     b->view.iters_add = (int)b->ungated_steps;
+    { const int ss = seed_solution(b); if (ss != RP_OK) return ss; }
     RP_HIP(rp::launch_solve(b->view, b->params, k, gap_tol, max_iter, b->stream));
     return RP_OK;
 }
@@ -597,6 +647,7 @@ int rp_batch_move_toward_feasibility(rp_batch *b)
 {
     RP_NEED_STATE(b);
     RP_HIP(rp::launch_move_toward_feasibility(b->view, b->params, b->stream));
+    b->sol_stale = true;
     return RP_OK;
 }
 
@@ -638,6 +689,7 @@ int rp_batch_bind_solution(rp_batch *b, rp_solution *d_out)
     if (!b) return fail(RP_ERR_INVALID, "null batch handle");
     if (((uintptr_t)d_out & 31u) != 0) return fail(RP_ERR_INVALID, "solution records must be 32-byte aligned");
     b->view.solution = reinterpret_cast<rp::Solution *>(d_out);
+    b->sol_stale = true;      // nothing in the new buffer is current: the next gated launch that skips finished problems seeds it first
     return RP_OK;
 }
 
@@ -710,7 +762,7 @@ int rp_batch_sample_device(rp_batch *b, double *d_pos66, double *d_acc4)
     RP_NEED_STATE(b);
     if (!d_pos66 || !d_acc4) return fail(RP_ERR_INVALID, "null output");
     if (((uintptr_t)d_pos66 & 15u) != 0) return fail(RP_ERR_INVALID, "d_pos66 must be 16-byte aligned (the positions are written as 16-byte vectors)");
-    if (b->view.scheduled && b->view.zero_end_vel && b->records_current && b->view.records) {
+    if (b->view.scheduled && b->view.zero_end_vel && b->records_current && !b->raw_positions_out && b->view.records) {
         // a whole scheduled batch whose positions are still the ones it was given: through problem-order records (two coalesced
         // sectors per problem) instead of the per-field gather; same arithmetic, same bits
         if (!b->d_solscratch) RP_HIP(hipMalloc((void **)&b->d_solscratch, b->view.n * sizeof(rp::Solution)));
@@ -803,6 +855,8 @@ int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr)
     }
     *d_ptr = (char *)b->view.base + (size_t)field * b->view.stride * elem_size(b->view.dtype);
     b->records_current = false;      // the caller may write through the pointer
+    b->sol_stale = true;
+    if (field >= 3 + rp::num_constraints(b->view.variant)) b->raw_positions_out = true;      // ... now or at any later time: sticky (see the struct)
     {   // a caller holding a raw pointer to an end-velocity field may write non-zero values the batch never sees: from
         // here on (until the next init / set_problems / set_state) the Newton kernels read vel0X and vel2X
         const int iv0 = 3 + rp::num_constraints(b->view.variant) + 1, iv2 = iv0 + 3;

@@ -177,6 +177,8 @@ class Oracle:
         L.orc_batch_solve_gated_ex.restype = ctypes.c_int64
         L.orc_batch_solve_gated_ex.argtypes = [ctypes.c_int, ctypes.c_size_t, _dp, ctypes.c_double, ctypes.c_int,
                                                ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_void_p]
+        L.orc_armijo_sides.argtypes = [ctypes.c_int, _dp, ctypes.c_int, ctypes.c_void_p, _dp]
+        L.orc_feasibility_margin.argtypes = [ctypes.c_int, _dp, ctypes.c_int, ctypes.c_void_p, _dp]
         L.orc_sample_trajectory.argtypes = [ctypes.c_int, _dp, _dp, _dp]
         L.orc_gen_problems.argtypes = [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, _dp, _dp, _dp]
         self.solver = None
@@ -248,6 +250,21 @@ class Oracle:
         d = np.zeros(3 + self.num_constraints(variant))
         self.lib.orc_step_ex(variant, _p(var), _p(d), ctypes.byref(info) if info is not None else None, self.solver)
         return d
+
+    def armijo_sides(self, variant, var, halvings):
+        """The residual test of the reference's second backtracking loop (onedpath_ip.cpp:941, onedpath2_ip.cpp:828) at the trial
+        made after `halvings` halvings, from the state `var` a step starts from: (|r(trial)|^2, |r(x)|^2 (1 - 0.01 s), s, largest
+        change of the first under a one-ulp move of one trial coordinate), or None beyond the loop's budget."""
+        out = np.zeros(4)
+        ok = self.lib.orc_armijo_sides(variant, _p(np.ascontiguousarray(var, dtype=np.float64)), int(halvings), self.solver, _p(out))
+        return tuple(out) if ok else None
+
+    def feasibility_margin(self, variant, var, halvings):
+        """The feasibility test of the first backtracking loop (onedpath_ip.cpp:919-928) at the trial made after `halvings`
+        halvings: (largest constraint value there, s, largest change of a constraint value under a one-ulp move of one variable)."""
+        out = np.zeros(3)
+        ok = self.lib.orc_feasibility_margin(variant, _p(np.ascontiguousarray(var, dtype=np.float64)), int(halvings), self.solver, _p(out))
+        return tuple(out) if ok else None
 
     def solve_gated(self, variant, var, tol=1e-8, max_iter=200):
         it = 0

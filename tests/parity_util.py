@@ -32,3 +32,54 @@ def keep_mask(n, ties):
     m = np.ones(n, dtype=bool)
     m[np.asarray(ties, dtype=int)] = False
     return m
+
+
+# ---- line-search decisions that differ from the oracle's: certified, not budgeted ---------------------------------------
+# Both backtracking loops compare a computed quantity with a threshold (onedpath_ip.cpp:919-928: constraint values against 0;
+# :932-945: |r(x + s d)|^2 against |r(x)|^2 (1 - 0.01 s)).  Two correct implementations that round differently (the device
+# condenses the KKT system and evaluates with fused multiply-adds) may decide a trial differently ONLY where that quantity lies
+# within rounding of its threshold.  "Within rounding" is made checkable by the oracle itself (orc_armijo_sides,
+# orc_feasibility_margin): the distance from the threshold at the first trial the two sides decide differently must not exceed
+# DECISION_TIE x what a ONE-ulp move of ONE coordinate of that trial point changes in the quantity (and, for the residual test,
+# never less than DECISION_TIE_ULPS ulps of the value: a trial point that has become x bit for bit may sit where no single
+# coordinate move registers).  Every differing decision is checked; one that is not a tie fails the test.
+DECISION_TIE = 4.0
+DECISION_TIE_ULPS = 8.0
+
+
+def certify_line_search_decisions(oracle, variant, states_before, nf_gpu, nr_gpu, nf_ref, nr_ref, strict=True):
+    """states_before: the states the compared step started from (rows, the oracle's layout).  Returns a dict with the number
+    of differing decisions of each loop and the certified distances (in units of the allowance: <= 1 is a tie).  strict=False
+    (tests/checks/decision_margins.py, the calibration run) collects the distances without asserting."""
+    nf_gpu, nr_gpu, nf_ref, nr_ref = (np.asarray(x, dtype=np.int64) for x in (nf_gpu, nr_gpu, nf_ref, nr_ref))
+    out = {"feas_diffs": 0, "resid_diffs": 0, "worst_feas": 0.0, "worst_resid": 0.0, "feas_ratios": [], "resid_ratios": []}
+    for i in np.nonzero((nf_gpu != nf_ref) | (nr_gpu != nr_ref))[0]:
+        row = np.ascontiguousarray(states_before[i], dtype=np.float64)
+        if nf_gpu[i] != nf_ref[i]:
+            # the first feasibility trial decided differently: its largest constraint value must sit within rounding of zero
+            # (after it the two searches walk different step lengths: the residual counts are then not comparable)
+            h = int(min(nf_gpu[i], nf_ref[i]))
+            m = oracle.feasibility_margin(variant, row, h)
+            assert m is not None, (i, nf_gpu[i], nf_ref[i])
+            worst, s, spread = m
+            ratio = abs(worst) / (DECISION_TIE * spread) if spread > 0 else np.inf
+            assert ratio <= 1.0 or not strict, \
+                "problem %d: feasibility halvings %d vs %d, but the oracle's largest constraint value at trial %d is %.3g, " \
+                "%.1f x the allowance (one-ulp spread %.3g)" % (i, nf_gpu[i], nf_ref[i], h, worst, ratio, spread)
+            out["feas_diffs"] += 1
+            out["feas_ratios"].append(ratio)
+            continue
+        h = int(min(nr_gpu[i], nr_ref[i]))
+        m = oracle.armijo_sides(variant, row, h)
+        assert m is not None, (i, nr_gpu[i], nr_ref[i])
+        lhs, rhs, s, spread = m
+        allow = max(DECISION_TIE * spread, DECISION_TIE_ULPS * np.spacing(abs(lhs)))
+        ratio = abs(lhs - rhs) / allow
+        assert ratio <= 1.0 or not strict, \
+            "problem %d: residual halvings %d vs %d, but at trial %d the oracle has |r(trial)|^2 = %.17g against %.17g: " \
+            "%.1f x the allowance (one-ulp spread %.3g)" % (i, nr_gpu[i], nr_ref[i], h, lhs, rhs, ratio, spread)
+        out["resid_diffs"] += 1
+        out["resid_ratios"].append(ratio)
+    out["worst_feas"] = max(out["feas_ratios"], default=0.0)
+    out["worst_resid"] = max(out["resid_ratios"], default=0.0)
+    return out

@@ -135,10 +135,16 @@ def test_bench_refuses_to_run_without_a_gpu():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no HIP device" in (r.stderr + r.stdout)
     assert "{" not in r.stdout          # no JSON line is ever printed from a CPU run
-    # `python bench.py --gpus 2` as typed (no RANK in the environment): the parent starts two ranks itself (torch.distributed.run)
-    # before it has touched torch or HIP; on a CPU box each rank then stops with "no HIP device" and the parent returns non-zero
+    # `python bench.py --gpus 2` as typed (no RANK in the environment): the parent -- which has not touched torch or HIP -- asks a fresh
+    # child how many HIP devices there are and refuses to start ranks that would have to share GPUs: exit code 3, a message
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 3 and "needs 2 HIP devices, this machine shows 0" in r.stderr and "starting 2 ranks" not in r.stderr
+    assert "{\"metric\"" not in r.stdout
+    # the debug form (all ranks on one device) skips that check: the parent starts two ranks itself (torch.distributed.run); on a CPU
+    # box each rank then stops with "no HIP device" and the parent returns non-zero
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=env)
     out = r.stderr + r.stdout
     assert r.returncode != 0

@@ -327,6 +327,14 @@ def test_two_rank_bench_rehearsal_on_one_device_covers_the_whole_batch(ranks):
     assert line["n_gpus"] == ranks and line["scaling"] == "weak" and "REHEARSAL" in line["data"] and line["cpu_baseline"] is None
     assert line["self_launched"] is True and line["ranks_in_process_group"] == ranks and "starting %d ranks" % ranks in out.stderr
     assert line["config"]["problems_total"] == ranks * per and line["config"]["converged_fraction"] == 1.0
+    # the line explains itself: per-rank launch times, the pieces of the timed region, the device of every rank --
+    # and says that this run's ranks shared one GPU
+    tb = line["timed_region_breakdown"]
+    assert len(tb["kernels_ms_per_rank"]) == ranks == len(tb["collective_ms_per_rank"]) == len(tb["barrier_ms_per_rank"]) == len(line["devices"])
+    assert 0 < tb["kernels_ms_min"] <= tb["kernels_ms_max"] <= tb["region_ms"] and tb["collective_ms_min"] >= 0
+    assert all(d.startswith("pci ") for d in line["devices"]) and len(set(line["devices"])) == 1
+    assert line["devices_distinct"] is False and "REHEARSAL" in line["devices_note"]
+    assert len(line["per_gpu_newton_steps_per_s"]) == ranks and all(x > 1e9 for x in line["per_gpu_newton_steps_per_s"])
     p0, p1, p2 = rp.problems.generate(12345, 0, ranks * per, rp.problems.DIST_MONOTONE)
     with rp.Batch(ranks * per) as b:
         b.set_problems(p0, p1, p2)
@@ -499,6 +507,72 @@ def test_solution_records_are_the_state_in_problem_order(variant, dtype):
             b.solution_device(0)
 
 
+def test_a_buffer_bound_late_is_complete_after_the_next_gated_solve():
+    # a gated launch writes the record of every problem it WORKS ON; a problem that finished in an earlier launch is
+    # skipped.  A buffer bound after a solve -- or records left behind by steps, nudges, a set_state -- must still be whole after
+    # the next gated solve ("after a gated solve every record is current", include/rp_batch.h): the launch is preceded by a pass
+    # that seeds the buffer from the state as it is.
+    from hip_util import DeviceBuffer
+    n = 3 * 4096 + 77
+    p0, p1, p2 = rp.problems.generate(4242, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as b, DeviceBuffer(32 * n, fill=0xff) as late, DeviceBuffer(32 * n, fill=0xff) as sep:
+        b.set_problems(p0, p1, p2)
+        b.solve(1e-8, 200, 0)                       # everything converges with nothing bound
+        b.bind_solution(late.ptr)
+        b.solve(1e-8, 200, 0)                       # no problem is worked on: every chunk returns at once
+        b.solution_device(sep.ptr)
+        assert np.array_equal(_records(late, n), _records(sep, n))
+        assert np.all(_records(late, n)["status"] == rp.ST_CONVERGED)
+        # a resumed solve: 6 gated steps, then (buffer bound in between) the rest in rounds -- problems that were done within the
+        # first launch are never touched again
+        late2 = DeviceBuffer(32 * n, fill=0xff)
+        b.bind_solution(None)
+        b.set_problems(p0, p1, p2)
+        b.solve_launch(1e-8, 200, 14)
+        b.bind_solution(late2.ptr)
+        b.solve(1e-8, 200, 4)
+        b.solution_device(sep.ptr)
+        rec = _records(late2, n)
+        assert np.array_equal(rec, _records(sep, n)) and rec["iters"].min() <= 14 < rec["iters"].max()
+        # ungated steps after a solve move every problem; the converged ones are skipped by the next solve, whose records must
+        # nevertheless be the state the steps left
+        b.step(2)
+        b.solve(1e-8, 200, 0)
+        b.solution_device(sep.ptr)
+        st = b.get_state()
+        rec = _records(late2, n)
+        assert np.array_equal(rec, _records(sep, n)) and np.array_equal(rec["duration0"], st[:, 1])
+        b.bind_solution(None)
+        late2.close()
+
+
+def test_positions_written_through_an_old_raw_pointer_are_seen_by_the_plot_data():
+    # rp_batch_sample_device reads a whole scheduled batch's positions from the records set_problems kept -- valid only
+    # while nobody can have written the position fields behind the batch's back.  A raw pointer to a constant field, once handed
+    # out, stays usable after later calls: the records path must stay off from then on.
+    from hip_util import DeviceBuffer
+    rp.load_library()
+    paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}, key=lambda p: "torch" in p)
+    hip = ctypes.CDLL(paths[0])
+    n = 2 * 4096 + 5
+    p0, p1, p2 = rp.problems.generate(99, 0, n, rp.problems.DIST_MONOTONE)
+    with rp.Batch(n) as b, DeviceBuffer(8 * 66 * n) as d_pos, DeviceBuffer(8 * 4 * n) as d_acc:
+        b.set_problems(p0, p1, p2)
+        ptr = b.field_ptr(13)                       # pos1X
+        b.set_problems(p0, p1, p2)                  # records current again ...
+        b.solve(1e-8, 200, 0)                       # ... and the state materialised: the old pointer is defined again
+        slot = b.slot_map()
+        moved = np.empty(n)
+        moved[slot] = p1 + 3.0                      # every middle node 3 units further on, written behind the batch's back
+        assert hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(moved.ctypes.data), ctypes.c_size_t(n * 8), 1) == 0
+        b.sample_device(d_pos.ptr, d_acc.ptr)
+        b.sync()
+        pos = d_pos.read(np.float64).reshape(n, 66)
+        host_pos, _ = b.sample()                    # the gather path
+        assert np.array_equal(pos, host_pos)
+        assert np.array_equal(pos[:, 32], p1 + 3.0) # segment 0 ends on the moved node
+
+
 def test_solution_records_of_identical_problems_in_identity_order():
     # init_default: no scheduled order (identical problems), the records are the positions themselves
     from hip_util import DeviceBuffer
@@ -610,5 +684,10 @@ def test_bench_with_a_forced_rccl_process_group_of_one_rank():
     assert forced["config"]["final_summary"] == plain["config"]["final_summary"]
     assert forced["config"]["newton_steps_per_pass_per_gpu"] == plain["config"]["newton_steps_per_pass_per_gpu"]
     assert forced["config"]["converged_fraction"] == 1.0 and forced["value"] > 0.3 * plain["value"]
+    for line in (plain, forced):      # the self-explaining keys are there at N = 1 too, with the one device named
+        tb = line["timed_region_breakdown"]
+        assert len(line["devices"]) == 1 and line["devices"][0].startswith("pci ") and line["devices_distinct"] is True and line["devices_note"] is None
+        assert 0 < tb["kernels_ms_max"] <= tb["region_ms"] and len(line["per_gpu_newton_steps_per_s"]) == 1
+    assert forced["timed_region_breakdown"]["collective_ms_min"] > 0.0      # the RCCL all-reduce really ran inside the region
     e2e = forced["end_to_end"]["with_solutions_in_problem_order"]
     assert e2e["both_forms_bitwise_equal"] is True and e2e["steps_summed_from_the_records"] == forced["end_to_end"]["newton_steps_per_batch"]

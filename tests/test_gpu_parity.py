@@ -14,7 +14,7 @@ import pytest
 
 import rocket_path_amd as rp
 from oracle_api import StepInfo
-from parity_util import certify_iteration_counts, keep_mask
+from parity_util import DECISION_TIE, certify_iteration_counts, certify_line_search_decisions, keep_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -346,6 +346,8 @@ def test_f4_fp32_single_steps(golden_dir):
     assert np.quantile(err, 0.99) < 2e-3
 
 
+F32_ALIKE_TOL = 2.0e-3      # pure fp32 against fp32 state + fp64 arithmetic on problems whose line-search decisions agree: the direction's
+                            # single-precision error, cond(K) x 6e-8 with cond(K) up to ~1e4 (profiles/r2_f4_fp32_error_tail.log), times s |dx| / |x| <= ~1
 F32_STATE_TOL = 1.0e-7      # 2^-24 = 5.96e-8 (rounding of the result to fp32) + what fp64 arithmetic disagrees on (2.4e-11 measured)
 
 
@@ -956,6 +958,7 @@ def test_f4_halving_counts_in_the_long_sequence_regime(oracle):
     aos = oracle.batch_init_feasible(rp.VARIANT_F4, p0, p1, p2)
     oracle.batch_steps(rp.VARIANT_F4, aos, 24)
     info = StepInfo()
+    before = aos.copy()
     with rp.Batch(n, rp.VARIANT_F4) as a:
         a.set_state(aos)
         nf, nr = a.step_counted(1)
@@ -969,9 +972,13 @@ def test_f4_halving_counts_in_the_long_sequence_regime(oracle):
     assert np.array_equal(nf, exp_nf), "%d feasibility counts differ" % int((nf != exp_nf).sum())
     # the residual loop of a stalled F4 problem ends where s dr drops below the rounding of |r|^2 (~50 halvings): that last-bit
     # decision differs between the condensed 3 x 3 solve and the reference's QR on a few problems per thousand (6 of 2,048
-    # measured), as in F3's post-convergence regime (profiles/r2_halving_probe.log); the feasibility counts above do not
+    # measured), as in F3's post-convergence regime (profiles/r2_halving_probe.log); the feasibility counts above do not.  Each
+    # such difference is CERTIFIED (parity_util.certify_line_search_decisions): at the first trial the two sides decide differently
+    # the oracle's own |r(trial)|^2 lies within DECISION_TIE one-ulp spreads of its threshold -- any other difference fails here
+    cert = certify_line_search_decisions(oracle, rp.VARIANT_F4, before, nf, nr, exp_nf, exp_nr)
+    print("F4 long-sequence regime: %d of %d residual counts differ, all certified ties (worst %.2f of the allowance of %g one-ulp spreads)"
+          % (cert["resid_diffs"], n, cert["worst_resid"], DECISION_TIE))
     same = nr == exp_nr
-    assert same.sum() >= n - n // 100, "%d residual counts differ" % int((~same).sum())
     assert serr(got[same, :3], aos[same, :3]) < 1e-9
 
 
@@ -1001,6 +1008,72 @@ def test_f4_wave_parallel_line_search_equals_single_steps_bitwise(dtype):
         assert np.array_equal(a.get_state(), b.get_state())
         assert np.all(a.get_iters()[0] == 36)
         assert (nr > 20).sum() > 30, (nr > 20).sum()      # ... so the service did run on the other side (fp64: ~1 % of the problems, fp32: a few dozen)
+
+
+@pytest.mark.parametrize("dist,steps", [(rp.problems.DIST_MONOTONE, 50), (rp.problems.DIST_NON_MONOTONE, 30)])
+def test_f3_line_search_decisions_through_the_post_convergence_regime_are_the_oracles_or_certified_ties(oracle, dist, steps):
+    # ADVICE r4 / VERDICT r4 next 3: beyond step ~19 F3's fixed-step launches search on affine pieces against their own value at
+    # s = 0 and count certain failures in closed form (newton_step_inplace<FROZEN>) -- and until this round only x and the
+    # multipliers were compared there.  Here every step of a fixed-step run, 1 .. `steps`, is taken from the ORACLE's state before
+    # that step, and both halving counts of every problem are the oracle's (onedpath_ip.cpp:927, :944) -- or the oracle's own test
+    # value at the first trial decided differently lies within DECISION_TIE one-ulp spreads of its threshold (a certified tie:
+    # parity_util.certify_line_search_decisions; anything else fails).  Also: the counts' totals, and the step itself at 1e-10.
+    n = 2048
+    p0, p1, p2 = rp.problems.generate(27182, 0, n, dist)
+    aos = oracle.batch_init_feasible(3, p0, p1, p2)
+    info = StepInfo()
+    diffs_f = diffs_r = tot_gpu = tot_orc = 0
+    worst_f = worst_r = 0.0
+    late = 0
+    with rp.Batch(n) as a:
+        for s in range(steps):
+            before = aos.copy()
+            a.set_state(aos)
+            nf, nr = a.step_counted(1)
+            got = a.get_state()
+            of, orr = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+            for i in range(n):
+                oracle.step(3, aos[i], info)
+                of[i], orr[i] = info.feas_halvings, info.resid_halvings
+            cert = certify_line_search_decisions(oracle, 3, before, nf, nr, of, orr)
+            diffs_f += cert["feas_diffs"]
+            diffs_r += cert["resid_diffs"]
+            worst_f, worst_r = max(worst_f, cert["worst_feas"]), max(worst_r, cert["worst_resid"])
+            tot_gpu += int(nr.sum())
+            tot_orc += int(orr.sum())
+            late += int((orr >= 40).sum())
+            assert serr(got[:, :3], aos[:, :3]) < TOL, s            # one step from the same state: the iterate itself
+    print("F3 dist %d: %d problem-steps through the post-convergence regime (%d with 40+ residual halvings): feasibility decisions that "
+          "differ %d (worst %.2f of the allowance), residual %d (worst %.2f); residual halvings in all: device %d, oracle %d"
+          % (dist, n * steps, late, diffs_f, worst_f, diffs_r, worst_r, tot_gpu, tot_orc))
+    assert late > (n * steps) // 4 if dist == rp.problems.DIST_MONOTONE else True      # the regime was reached
+    assert abs(tot_gpu - tot_orc) <= 0.002 * tot_orc                                   # the totals agree to 0.2 %
+
+
+def test_f4_pure_fp32_decisions_against_fp32_state_and_a_bound_for_every_problem_that_decides_alike(golden_dir):
+    # VERDICT r4 missing 4 / weak 1b: pure fp32 arithmetic had a statistical bound only.  One step from the 4,096 golden
+    # fp32-representable states in both modes: RP_DTYPE_F32_STATE (fp64 arithmetic: every problem within 1e-7 of the fp64 oracle,
+    # test above) and RP_DTYPE_F32.  Where BOTH halving counts of a problem agree, the two took the same line-search decisions
+    # and differ by single-precision arithmetic of the direction alone: those problems are bounded PER PROBLEM; the others
+    # ("flipped": an Armijo or feasibility decision below fp32 resolution went the other way, SURVEY C5 / DESIGN section 4) are counted
+    # and reported, and their share is bounded.
+    t = np.load(os.path.join(golden_dir, "f4_steps.npz"))
+    n = len(t["state_in"])
+    with rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32_STATE) as a, rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32) as b:
+        a.set_state(t["state_in"])
+        b.set_state(t["state_in"])
+        nfa, nra = a.step_counted(1)
+        nfb, nrb = b.step_counted(1)
+        sa, sb = a.get_state(), b.get_state()
+    alike = (nfa == nfb) & (nra == nrb)
+    err = np.max(np.abs(sb[:, :3] - sa[:, :3]) / np.maximum(np.abs(sa[:, :3]), 1.0), axis=1)
+    flipped = float((~alike).mean())
+    print("pure fp32 against fp32 state + fp64 arithmetic, one step from %d states: %.2f %% of the problems take another line-search decision; "
+          "the others differ by at most %.2e (median %.1e, 99 %% %.1e); the flipped ones by at most %.2e"
+          % (n, 100 * flipped, err[alike].max(), np.median(err[alike]), np.quantile(err[alike], 0.99), err[~alike].max() if flipped else 0.0))
+    assert np.all(np.isfinite(sb))
+    assert flipped < 0.10
+    assert err[alike].max() < F32_ALIKE_TOL
 
 
 # ---------------------------------------------------------------- round 4: sweeps that were hand-run scripts, now in the suite
@@ -1047,25 +1120,32 @@ def test_f4_feasibility_decisions_step_by_step_from_the_oracles_states(oracle, d
     oracle.batch_steps(rp.VARIANT_F4, aos, first_step, threads=0)
     info = StepInfo()
     tot_f = long_seq = bad_f = bad_r = 0
+    worst = 0.0
     with rp.Batch(n, rp.VARIANT_F4, dtype) as a, rp.Batch(n, rp.VARIANT_F4, dtype) as b:
         for s in range(steps):
             if dtype != rp.DTYPE_F64:
                 aos[:] = aos.astype(np.float32).astype(np.float64)      # what the batch will hold (state and constants)
+            before = aos.copy()
             a.set_state(aos)
             b.set_state(aos)
             nf, nr = a.step_counted(1)
             b.step(1)
             assert np.array_equal(a.get_state(), b.get_state()), s       # proofs on == every trial evaluated
+            of, orr = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
             for i in range(n):
                 oracle.step(rp.VARIANT_F4, aos[i], info)
-                tot_f += info.feas_halvings
-                long_seq += int(info.feas_halvings >= 10)
-                bad_f += int(nf[i] != info.feas_halvings)
-                bad_r += int(nr[i] != info.resid_halvings)
-    print("F4 dtype %d: %d problem-steps, %d feasibility halvings, %d sequences of ten or more; feasibility counts that differ: %d, residual: %d"
-          % (dtype, n * steps, tot_f, long_seq, bad_f, bad_r))
+                of[i], orr[i] = info.feas_halvings, info.resid_halvings
+            tot_f += int(of.sum())
+            long_seq += int((of >= 10).sum())
+            bad_f += int((nf != of).sum())
+            # every residual count that differs is a certified tie: the oracle's own test value within DECISION_TIE one-ulp spreads
+            # of its threshold at the first trial decided differently (no budget for "last-bit decisions")
+            cert = certify_line_search_decisions(oracle, rp.VARIANT_F4, before, nf, nr, of, orr)
+            bad_r += cert["resid_diffs"]
+            worst = max(worst, cert["worst_resid"])
+    print("F4 dtype %d: %d problem-steps, %d feasibility halvings, %d sequences of ten or more; feasibility counts that differ: %d, residual: %d "
+          "(every one a certified tie, worst %.2f of the allowance)" % (dtype, n * steps, tot_f, long_seq, bad_f, bad_r, worst))
     assert long_seq > n * steps // 8 and bad_f == 0
-    assert bad_r <= n * steps // 100                                     # last-bit decisions of stalled problems, as in the tests above
 
 
 @pytest.mark.parametrize("dtype", [rp.DTYPE_F64, rp.DTYPE_F32_STATE, rp.DTYPE_F32])
