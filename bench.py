@@ -225,6 +225,10 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: run the N-rank code path with every rank on device 0 and gloo for the collectives "
                          "(RCCL refuses two ranks on one GPU); numbers from such a run are not benchmark results")
+    ap.add_argument("--condition-launches", type=int, default=240,
+                    help="untimed solves of scratch batches right before the W warmup passes (0: none).  From an idle chip the power "
+                         "controller over-reacts for ~20 ms (launches at 0.19 -> 0.23 -> 0.17 ms, profiles/r5_transient.log): a timed region "
+                         "of 20 launches that starts 1 ms after idle measures that transient, not the path.  240 launches are ~40 ms")
     ap.add_argument("--sustain-seconds", type=float, default=0.0,
                     help="extra, after the timed region: keep solving batches back to back for at least this many seconds and report the "
                          "steady-state rate with clock / power samples (rocm-smi) -- the thermal-steady figure the 4 ms timed region cannot show")
@@ -295,11 +299,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup: W untimed passes ----
+    # ---- untimed: communicator set-up, conditioning, then the W warmup passes ----
+    if grouped:
+        sharding.allreduce_summary(summary.clone().to(coll_dev), force=True)     # RCCL communicator setup outside the timed region ...
+        barrier()                                                                # ... and before the conditioning: it idles the GPU for a while
+    # Conditioning: the chip is brought to the clocks it HOLDS under this load before anything is timed.  From idle the power
+    # controller first over-reacts (a launch takes 0.19 ms, then 0.21-0.23 ms between 2 and 6 ms, then settles at 0.17 ms after ~20 ms:
+    # profiles/r5_transient.log; 50 ms of idling bring the whole transient back), so a K = 20 region one millisecond after idle times the
+    # controller, not the kernel.  The scratch batches are not among the timed ones; `cold_start` below reports the other figure.
+    scratch = [rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) for _ in range(min(8, max(args.condition_launches, 0)))]
+    for b in scratch:
+        b.set_problems_device(*ptrs)
+
+    def condition(launches=None):
+        n_launch = args.condition_launches if launches is None else launches
+        for j in range(n_launch if scratch else 0):
+            b = scratch[j % len(scratch)]
+            b.restart()
+            b.solve(GAP_TOL, MAX_ITER, 0)
+    condition()
     for i in range(W):
         pass_(i)
-    if grouped:
-        sharding.allreduce_summary(summary.clone().to(coll_dev), force=True)     # RCCL communicator setup outside the timed region
     barrier()
 
     # ---- timed: exactly K passes, then the final summary reduction (+ all-reduce) ----
@@ -412,6 +432,9 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
+        "conditioning": {"untimed_solves_before_the_warmup": args.condition_launches if scratch else 0,
+                         "why": "steady-state clocks: the power controller's transient after idle lasts ~20 ms (profiles/r5_transient.log); "
+                                "`cold_start` is the same K launches from an idle chip"},
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo collectives -- not a result)",
         "config": {
             "workload": "BASELINE configs[2] (C3): %d F3 onedpath_ip problems per GPU, convergence-gated "
@@ -461,13 +484,25 @@ def main():
     }
 
     # ---- opt-in: the steady state (--sustain-seconds S).  The timed region above is ~4 ms, half of it before the power controller has
-    # reacted; here the pool's batches are solved back to back for at least S seconds (per round: every batch put back on its start,
-    # untimed by the events, then every batch solved, HIP-event timed), with rocm-smi sampled beside it ----
+    # reacted.  Here a LARGE pool of batches (up to 512 x 136 MB: HBM holds them) is solved back to back -- ~0.1 s of uninterrupted
+    # fp64 solves per round, HIP-event timed, its second half separately -- then every batch is put back on its start (memory-bound,
+    # ~8 % of a round) and the next round follows, for at least S seconds, with rocm-smi sampled beside it ----
     def sustain(seconds):
         import csv
         import io
         import subprocess
         import threading
+        free_b, _total_b = torch.cuda.mem_get_info()
+        per_batch = 200e6 * (count / float(N_PER_GPU))                     # fields + progress words + records + maps, generously
+        n_big = int(max(len(batches), min(512, 0.6 * free_b / max(per_batch, 1.0))))
+        big = list(batches)
+        try:
+            while len(big) < n_big:
+                nb = rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream)
+                nb.set_problems_device(*ptrs)
+                big.append(nb)
+        except rp.RpError:
+            pass                                                           # as many as fit
         samples, stop = [], [False]
 
         def poll():
@@ -487,16 +522,19 @@ def main():
         rounds = []
         lead.sync()
         t_start = time.perf_counter()
+        halfway = len(big) // 2
         while True:
-            for b in batches:
+            for b in big:
                 b.restart()
             lead.event_record(2)
-            for b in batches:
+            for j, b in enumerate(big):
+                if j == halfway:
+                    lead.event_record(7)
                 b.solve(GAP_TOL, MAX_ITER, 0)
             lead.event_record(3)
             lead.sync()
             now = time.perf_counter()
-            rounds.append((now - t_start, lead.event_elapsed_ms(2, 3) / len(batches)))
+            rounds.append((now - t_start, lead.event_elapsed_ms(2, 3) / len(big), lead.event_elapsed_ms(7, 3) / (len(big) - halfway)))
             if now - t_start >= seconds:
                 break
         t_stop = time.perf_counter()
@@ -504,33 +542,44 @@ def main():
         stop[0] = True
         th.join()
         spl = steps_local / max(K, 1)
-        late = [ms for t, ms in rounds if t >= 0.5 * rounds[-1][0]] or [rounds[-1][1]]
+        late = [r for r in rounds if r[0] >= 0.5 * rounds[-1][0]] or [rounds[-1]]
+        ms_whole, ms_half = float(np.mean([r[1] for r in late])), float(np.mean([r[2] for r in late]))
 
         def numeric(window):
             cols = {}
             for _, d in window:
                 for k, v in d.items():
                     try:
-                        cols.setdefault(k, []).append(float(str(v).strip("()MHzWCmVc% ")))
+                        x = float(str(v).strip("()MHhzWCmVc% "))
                     except ValueError:
-                        pass
+                        continue
+                    cols.setdefault(k, []).append(x)
             return {k: {"min": min(v), "median": float(np.median(v)), "max": max(v)} for k, v in cols.items() if k.lower() != "device"}
         under = [x for x in samples if t_start + 0.5 * (t_stop - t_start) <= x[0] <= t_stop]
         idle = [x for x in samples if x[0] < t_start]
-        return {"seconds": t_stop - t_start, "rounds": len(rounds), "batches_per_round": len(batches),
-                "ms_per_launch_first_round": rounds[0][1], "ms_per_launch_second_half": float(np.mean(late)),
-                "steady_newton_steps_per_s": spl / (float(np.mean(late)) * 1e-3),
-                "wall_clock_newton_steps_per_s_including_the_restarts": spl * len(batches) * len(rounds) / (t_stop - t_start),
-                "rocm_smi_idle_before": numeric(idle), "rocm_smi_second_half_under_load": numeric(under), "rocm_smi_samples": len(samples),
-                "note": "per round every pool batch is put back on its feasible start (k_restart_feasible, outside the events) and then solved "
-                        "(k_solve_chunks, HIP events around the solves only); the GPU runs the fp64 solve ~90 % of the window"}
+        smi = numeric(under)
+        power = next((v["median"] for k, v in smi.items() if "power" in k.lower()), None)
+        for nb in big[len(batches):]:
+            nb.close()
+        return {"seconds": t_stop - t_start, "rounds": len(rounds), "batches_per_round": len(big),
+                "uninterrupted_solve_ms_per_round": ms_whole * len(big),
+                "ms_per_launch_first_round": rounds[0][1], "ms_per_launch_later_rounds": ms_whole, "ms_per_launch_second_half_of_later_rounds": ms_half,
+                "steady_newton_steps_per_s": spl / (ms_half * 1e-3),
+                "wall_clock_newton_steps_per_s_including_the_restarts": spl * len(big) * len(rounds) / (t_stop - t_start),
+                "joule_per_newton_step_at_median_power": (power / (spl / (ms_whole * 1e-3))) if power else None,
+                "rocm_smi_idle_before": numeric(idle), "rocm_smi_second_half_under_load": smi, "rocm_smi_samples": len(samples),
+                "rocm_smi_last_sample_raw": (under[-1][1] if under else None),
+                "note": "per round every batch of a large pool is put back on its feasible start (k_restart_feasible, outside the events, ~8 % of the "
+                        "round: the chip sees a short memory-bound breather there) and then all are solved back to back (k_solve_chunks, HIP events "
+                        "around the solves only; the second half of each solve phase timed separately); steady = second halves of the later rounds"}
 
     # ---- end to end: bare positions -> solutions, per fresh batch (nothing precomputed), HIP-event timed ----
     def end_to_end(reps):
         use = batches[:min(len(batches), reps)]
-        for b in use[:2]:                     # untimed: first-use allocations of the scheduling scratch are long done; clocks
+        for b in use[:2]:                     # untimed: first-use allocations of the scheduling scratch are long done
             b.set_problems_device(*ptrs)
             b.solve(GAP_TOL, MAX_ITER, 0)
+        condition()                           # steady clocks, as for the headline (the loops below follow each other without idling)
         lead.sync()
         lead.event_record(2)
         for b in use:
@@ -765,6 +814,7 @@ def main():
                 for _ in range(3):
                     c5.set_problems_device(*ptrs)
                     c5.restart()
+                    condition(120)           # (the 50-step launch is arithmetic-bound for 1-1.5 ms: steady clocks for it too)
                     c5.sync()
                     c5.event_record(4)
                     c5.step(50)
@@ -867,6 +917,21 @@ def main():
                                  "roofline": feas_roofline(t_f, n7),
                                  "note": "16 fields read, 3 written per problem; the arithmetic (Gram matrix, Eigen-ordered 4 x 4 column-pivoted "
                                          "Householder QR in double precision, one problem per lane) is what the launch time is made of"}}
+
+    # the same K launches from an IDLE chip (0.3 s of nothing first): what the timed region measured before it was conditioned
+    if not args.no_extras:
+        for j in range(min(K, n_batches)):
+            batches[j].restart()
+        lead.sync()
+        time.sleep(0.3)
+        lead.event_record(2)
+        for j in range(min(K, n_batches)):
+            batches[j].solve(GAP_TOL, MAX_ITER, 0)
+        lead.event_record(3)
+        lead.sync()
+        cold_ms = lead.event_elapsed_ms(2, 3) / min(K, n_batches)
+        line["cold_start"] = {"launches": min(K, n_batches), "ms_per_launch": cold_ms, "newton_steps_per_s": steps_per_launch / (cold_ms * 1e-3),
+                              "note": "the K launches issued after 0.3 s of idling: inside the power controller's transient"}
 
     if args.sustain_seconds > 0:
         line["sustained"] = sustain(args.sustain_seconds)

