@@ -29,6 +29,36 @@ def one(d, pat):
 
 if stats_dir != "-":      # "-": the counter summaries only (collect_r4.sh folds them before the kernel-trace pass, which needs them)
     shutil.copy(one(stats_dir, "*_kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_kernel_stats.csv" % tag))
+    # The timed launches themselves, out of the same trace.  The per-kernel statistics above average EVERY launch of a kernel -- for the
+    # benchmark's kernel that is the conditioning (which starts inside the power controller's transient), the warmup, the K timed
+    # launches, the cold-start extra ...; the K timed ones are the launches of k_solve_chunks<double, double, 3, false, true, 0, false> right
+    # before the FIRST k_reduce_partial of the run (the final reduction follows them in stream order).
+    try:
+        rows = sorted(csv.DictReader(open(one(stats_dir, "*_kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
+        TIMED = "k_solve_chunks<double, double, 3, false, true, 0, false>"
+        first_reduce = next(i for i, r in enumerate(rows) if "k_reduce_partial" in r["Kernel_Name"])
+        before = [r for r in rows[:first_reduce] if TIMED in r["Kernel_Name"] and int(r["Grid_Size_X"]) == N]
+        bench_line = None
+        try:
+            bench_line = json.loads([l for l in open(os.path.join(os.path.dirname(os.path.normpath(stats_dir)), "bench_under_rocprof.json")) if l.startswith("{")][-1])
+        except Exception:
+            pass
+        K = int(bench_line["steps"]) if bench_line else 20
+        W = int(bench_line["warmup"]) if bench_line else 5
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in before]
+        timed, warm, cond = dur[-K:], dur[-(K + W):-K], dur[:-(K + W)]
+        every = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if TIMED in r["Kernel_Name"] and int(r["Grid_Size_X"]) == N]
+        json.dump({"_what": "the K timed launches of `python3 bench.py --gpus 1 --steps %d --warmup %d` under rocprofv3 --kernel-trace, told apart from the other "
+                            "launches of the same kernel by their place in the trace (the K right before the first k_reduce_partial)" % (K, W),
+                   "kernel": TIMED, "timed_launch_ns": timed, "timed_avg_ns": sum(timed) / max(len(timed), 1),
+                   "warmup_avg_ns": (sum(warm) / len(warm)) if warm else None,
+                   "conditioning_launches": len(cond), "conditioning_first_20_avg_ns": (sum(cond[:20]) / len(cond[:20])) if cond else None,
+                   "conditioning_last_20_avg_ns": (sum(cond[-20:]) / len(cond[-20:])) if cond else None,
+                   "all_launches_of_this_kernel": len(every), "all_launches_avg_ns": sum(every) / max(len(every), 1),
+                   "bench_line_avg_launch_ms_same_run": (bench_line or {}).get("roofline", {}).get("avg_launch_ms")},
+                  open(os.path.join(ROOT, "profiles", "%s_timed_launches.json" % tag), "w"), indent=1)
+    except Exception as exc:      # an older trace layout: the statistics file stands alone
+        print("timed launches not extracted:", exc)
 
 
 def counters(d, grid=None):
