@@ -28,5 +28,5 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 --sustain-seconds 3 > $O/bench.j
 rm -f $O/bench_5runs.jsonl
 for i in 1 2 3 4 5; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline >> $O/bench_5runs.jsonl 2>> $O/bench.err; done
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --force-process-group > $O/bench_forced_rccl.json 2>> $O/bench.err
-cp profiles/r5_sq_counters.json profiles/r5_hbm_traffic.json profiles/r5_sources.json profiles/r5_bench_kernel_stats.csv $O/
+cp profiles/r5_sq_counters.json profiles/r5_hbm_traffic.json profiles/r5_sources.json profiles/r5_bench_kernel_stats.csv profiles/r5_timed_launches.json $O/
 echo collected
