@@ -1317,8 +1317,9 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
                         // One lane writes its 13 + 2 NC values, every lane reads them back (a broadcast read: one address, no bank
                         // conflict): LDS instructions, which issue beside the other waves' arithmetic, where 2 x 21 v_readlane and the
                         // moves that bring their scalar results back into vector registers were a third of the service's vector
-                        // instructions.  The kernel's blocks are single waves (k_steps_chunks), and a wave's LDS operations complete in
-                        // order: no barrier.
+                        // instructions.  The kernel's blocks are single waves (k_steps_chunks: kChunkBlock, with a static_assert at the one
+                        // place this WAVE form is instantiated), and a wave's LDS operations complete in order: no barrier.  Any other launch
+                        // shape (the 256-thread streaming kernels share run_lane) must not instantiate WAVE: four waves would race on s_bc.
                         __shared__ T s_bc[13 + 2 * NC];
                         LdsBackup<T> bc = (LdsBackup<T>)s_bc;
                         if (lane_id == src) {

@@ -479,8 +479,12 @@ template <int VARIANT, bool REGBK> constexpr int kStepsChunkWaves = (kStepInPlac
 // that cannot fill three waves per SIMD anyway (launch_steps picks it below 196,608 problems): a lone wave has nothing to run
 // under an LDS round trip, and the post-convergence regime of a fixed-step run (BASELINE configs[1], 65,536 problems x 50 steps)
 // makes one per halving.  Same arithmetic, same bits.
+// kChunkBlock: threads per block of the chunk kernels = ONE wave.  newton_step_to<WAVE> (F4's fixed-step launches) broadcasts a straggler's
+// search state through one LDS area per BLOCK with no barrier -- correct only because the block is a single wave, whose LDS operations complete
+// in order; the static_assert below ties that code to this launch shape (in a 256-thread kernel four waves would race on it).
+constexpr int kChunkBlock = 64;
 template <typename S, typename T, int VARIANT, bool ZV, bool REGBK = false>
-__global__ void __launch_bounds__(64, (kStepsChunkWaves<VARIANT, REGBK>))
+__global__ void __launch_bounds__(kChunkBlock, (kStepsChunkWaves<VARIANT, REGBK>))
 k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, unsigned lanes)
 {
     constexpr int NC = CMap<VARIANT>::NC;
@@ -533,6 +537,7 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     } else {
     // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
     // its stalled problems), so all its fixed-step kernels use it and agree bit for bit
+    static_assert(kChunkBlock == 64, "newton_step_to<WAVE> broadcasts through LDS without a barrier: single-wave blocks only");
     run_lane<T, VARIANT, false, false, Pk, S, kAffine<VARIANT>, 0, RP_WAVE_LS && (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
     }
     // the store addresses are formed only now: the barrier keeps the compiler from holding eleven of them in registers
@@ -1317,11 +1322,11 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
             constexpr unsigned lanes = 64u;
 #endif
             const dim3 grid((unsigned)((b.n + lanes - 1) / lanes));
-            if (b.zero_end_vel) { constexpr bool Z = true;  RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), grid, dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3), lanes)); }
-            else                { constexpr bool Z = false; RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), grid, dim3(64), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3), lanes)); }
+            if (b.zero_end_vel) { constexpr bool Z = true;  RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), grid, dim3(kChunkBlock), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3), lanes)); }
+            else                { constexpr bool Z = false; RP_DISPATCH_ST(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V3, Z, true>), grid, dim3(kChunkBlock), 0, stream, (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V3), lanes)); }
             return hipGetLastError();
         }
-        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V, Z>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, stream,
+        RP_DISPATCH_Z(b, hipLaunchKernelGGL((k_steps_chunks<S, T, V, Z>), dim3((unsigned)((b.n + 63) / 64)), dim3(kChunkBlock), 0, stream,
                                              (S *)b.base, b.stride, b.n, k, make_kparams<T>(hp, V), 64u));
         return hipGetLastError();
     }
