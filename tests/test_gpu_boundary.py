@@ -684,6 +684,8 @@ def test_bench_with_a_forced_rccl_process_group_of_one_rank():
     assert forced["config"]["final_summary"] == plain["config"]["final_summary"]
     assert forced["config"]["newton_steps_per_pass_per_gpu"] == plain["config"]["newton_steps_per_pass_per_gpu"]
     assert forced["config"]["converged_fraction"] == 1.0 and forced["value"] > 0.3 * plain["value"]
+    for line in (plain, forced):      # the timed region starts on a conditioned chip, and the line says so
+        assert line["conditioning"]["untimed_solves_before_the_warmup"] == 160
     for line in (plain, forced):      # the self-explaining keys are there at N = 1 too, with the one device named
         tb = line["timed_region_breakdown"]
         assert len(line["devices"]) == 1 and line["devices"][0].startswith("pci ") and line["devices_distinct"] is True and line["devices_note"] is None
