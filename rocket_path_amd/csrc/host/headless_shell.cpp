@@ -103,6 +103,12 @@ int main(int argc, char **argv)
                    br.stepsTotal / br.seconds, gpus, benchPasses, benchWarmup, br.msPerPass, f32 ? "f32" : "f64", perGpu, n,
                    br.stepsTotal / benchPasses, br.converged, br.maxGap, br.maxResidualSq);
             for (size_t d = 0; d < br.deviceMs.size(); ++d) printf("%s%.6g", d ? ", " : "", br.deviceMs[d]);
+            printf("], \"devices\": [");      // which GPU every shard really sat on (rp_device_id: PCI bus id + UUID), as bench.py prints it
+            for (int d = 0; d < gpus; ++d) {
+                char id[128] = "?";
+                if (rp_device_id(d, id, sizeof id) != RP_OK) snprintf(id, sizeof id, "device %d: %s", d, rp_last_error());
+                printf("%s\"%s\"", d ? ", " : "", id);
+            }
             printf("]}\n");
             return 0;
         }

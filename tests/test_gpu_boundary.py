@@ -240,6 +240,7 @@ def test_single_process_sharded_bench_prints_the_bench_keys():
     assert line["config"]["newton_steps_per_pass"] == r["total_steps"] and line["config"]["converged"] == n
     assert line["config"]["max_gap"] < 1e-8 and line["value"] > 1e9
     assert len(line["per_device_ms_per_pass"]) == 1 and 0 < line["per_device_ms_per_pass"][0] <= line["ms_per_step"] * 1.001
+    assert len(line["devices"]) == 1 and line["devices"][0].startswith("pci ") and line["devices"][0] == rp.device_id(0)
 
 
 _GLOBAL_CHECK_SCRIPT = r"""
