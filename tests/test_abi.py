@@ -63,6 +63,15 @@ def test_invalid_arguments_are_rejected_without_a_device():
     assert lib.rp_batch_destroy(None) == capi.RP_OK
     n = ctypes.c_size_t()
     assert lib.rp_batch_size(None, ctypes.byref(n)) == capi.RP_ERR_INVALID
+    # rp_device_id (ABI revision 5): a short buffer or none is refused before any device is asked
+    small = ctypes.create_string_buffer(8)
+    assert lib.rp_device_id(0, small, 8) == capi.RP_ERR_INVALID
+    assert lib.rp_device_id(0, None, 128) == capi.RP_ERR_INVALID
+    if rp.device_count() == 0:
+        buf = ctypes.create_string_buffer(128)
+        assert lib.rp_device_id(0, buf, 128) == capi.RP_ERR_NO_DEVICE and b"no HIP device" in lib.rp_last_error()
+        with pytest.raises(rp.RpError):
+            rp.device_id(0)
 
 
 @pytest.mark.skipif(rp.device_count() > 0, reason="a GPU is present: the no-device path cannot be exercised")
