@@ -14,7 +14,7 @@ oracle = Oracle()
 info = StepInfo()
 print("FEAS_TIE = %g x (one-ulp spread + second-solver spread); RESID_TIE = %g x (spread of |r(trial)|^2 + spread of the threshold + second-solver "
       "spread), never below %g ulps" % (FEAS_TIE, RESID_TIE, RESID_TIE_ULPS))
-SEEDS = (31415, 27182, 2718, 16180)      # (the tests' own seeds among them)
+SEEDS = tuple(int(x) for x in os.environ.get("SEEDS", "31415,27182,2718,16180").split(","))      # (default: the tests' own seeds among them; needs >= 4)
 for variant, dtype, first, steps, n, dist, seed in [(4, rp.DTYPE_F64, 18, 10, 4096, 0, sd) for sd in SEEDS[:2]] + [(4, rp.DTYPE_F32_STATE, 18, 10, 4096, 0, SEEDS[0]),
                                                     (4, rp.DTYPE_F64, 24, 1, 2048, 0, 2718)] + \
         [(3, rp.DTYPE_F64, 0, 50, 2048, 0, sd) for sd in SEEDS] + [(3, rp.DTYPE_F64, 0, 30, 2048, 2, sd) for sd in SEEDS] + \
