@@ -929,6 +929,43 @@ def main():
                                  "note": "16 fields read, 3 written per problem; the arithmetic (Gram matrix, Eigen-ordered 4 x 4 column-pivoted "
                                          "Householder QR in double precision, one problem per lane) is what the launch time is made of"}}
 
+    # The headline workload with its batches dealt alternately onto TWO streams: the next launch's first (longest) chunks fill the wave slots
+    # the previous launch's last chunks leave empty (wave slots stand empty 18 % of a launch at its two ends).  What a caller gains who keeps
+    # two streams busy; wall clock (events of one stream do not span two), steady clocks, the one-stream figure measured the same way beside it.
+    if not args.no_extras:
+        try:
+            m = max(2, min(n_batches, 40) // 2 * 2)
+            first = batches[:m // 2]
+            other = rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank)                       # its own stream
+            second = [other] + [rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=other.stream()) for _ in range(m // 2 - 1)]
+            onestream = [rp.Batch(count, rp.VARIANT_F3, rp.DTYPE_F64, device=local_rank, stream=stream) for _ in range(m // 2)]
+            for b in second + onestream:
+                b.set_problems_device(*ptrs)
+
+            def burst(bs):
+                for b in bs:
+                    b.restart()
+                condition()
+                lead.sync()
+                other.sync()
+                t_b = time.perf_counter()
+                for b in bs:
+                    b.solve(GAP_TOL, MAX_ITER, 0)
+                lead.sync()
+                other.sync()
+                return (time.perf_counter() - t_b) / len(bs) * 1e3
+            ms_one = min(burst(first + onestream) for _ in range(2))
+            ms_two = min(burst([x for pair in zip(first, second) for x in pair]) for _ in range(2))
+            line["two_streams"] = {"launches": m, "ms_per_batch": ms_two, "newton_steps_per_s": steps_per_launch / (ms_two * 1e-3),
+                                   "one_stream_same_method_ms_per_batch": ms_one, "gain": ms_one / ms_two,
+                                   "note": "wall clock over %d launches after conditioning, host enqueue and the final synchronisation included in both "
+                                           "figures; kernels of the two streams overlap, so per-kernel durations exceed the time per batch -- which is why "
+                                           "the headline stays on one stream (profiles/r5_tuning.md)" % m}
+            for b in second + onestream:
+                b.close()
+        except Exception as exc:      # an extra: never takes the benchmark down
+            line["two_streams"] = {"error": str(exc)}
+
     # the same K launches from an IDLE chip (0.3 s of nothing first): what the timed region measured before it was conditioned
     if not args.no_extras:
         for j in range(min(K, n_batches)):
