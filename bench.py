@@ -229,9 +229,10 @@ def main():
                     help="untimed solves of scratch batches (one each, back to back) right before the W warmup passes (0: none).  From an idle "
                          "chip the power controller over-reacts for ~20 ms (launches at 0.19 -> 0.23 -> 0.17 ms, profiles/r5_transient.log): a "
                          "timed region of 20 launches that starts 1 ms after idle measures that transient, not the path.  160 launches are ~28 ms")
-    ap.add_argument("--sustain-seconds", type=float, default=0.0,
+    ap.add_argument("--sustain-seconds", type=float, default=None,
                     help="extra, after the timed region: keep solving batches back to back for at least this many seconds and report the "
-                         "steady-state rate with clock / power samples (rocm-smi) -- the thermal-steady figure the 4 ms timed region cannot show")
+                         "steady-state rate with clock / power samples (the device's hwmon files) -- the thermal-steady figure the 4 ms timed region cannot show.  "
+                         "Default: 1.5 s on a single-GPU run with extras (it is also what lets an outside sampler see the GPU busy), 0 otherwise")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -491,11 +492,8 @@ def main():
     # ---- opt-in: the steady state (--sustain-seconds S).  The timed region above is ~4 ms, half of it before the power controller has
     # reacted.  Here a LARGE pool of batches (up to 512 x 136 MB: HBM holds them) is solved back to back -- ~0.1 s of uninterrupted
     # fp64 solves per round, HIP-event timed, its second half separately -- then every batch is put back on its start (memory-bound,
-    # ~8 % of a round) and the next round follows, for at least S seconds, with rocm-smi sampled beside it ----
+    # ~8 % of a round) and the next round follows, for at least S seconds, with the device's hwmon files (clock, power, temperature) sampled beside it ----
     def sustain(seconds):
-        import csv
-        import io
-        import subprocess
         import threading
         free_b, _total_b = torch.cuda.mem_get_info()
         per_batch = 200e6 * (count / float(N_PER_GPU))                     # fields + progress words + records + maps, generously
@@ -509,18 +507,28 @@ def main():
         except rp.RpError:
             pass                                                           # as many as fit
         samples, stop = [], [False]
+        # Clock, power and temperature straight from the amdgpu hwmon files of THIS device (found by the PCI bus id rp_device_id reports).
+        # No child process: a process that has initialised the GPU must not fork-and-exec helpers (rocm-smi is a `#!/usr/bin/env python3`
+        # script: under rocprofv3 its second exec is exactly the hop the GPU boxes refuse).
+        import glob
+        pci = (rp.device_id(local_rank).split() + ["", ""])[1].lower()
+        hw = sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % pci))
+        fields = (("power_W", "power1_input", 1e-6), ("power_W", "power1_average", 1e-6), ("sclk_MHz", "freq1_input", 1e-6), ("mclk_MHz", "freq2_input", 1e-6),
+                  ("junction_C", "temp2_input", 1e-3), ("memory_C", "temp3_input", 1e-3), ("power_cap_W", "power1_cap", 1e-6))
 
         def poll():
             while not stop[0]:
-                try:
-                    out = subprocess.run(["rocm-smi", "-d", str(local_rank), "--showpower", "--showclocks", "--showtemp", "--csv"],
-                                         capture_output=True, text=True, timeout=5).stdout
-                    rows = list(csv.reader(io.StringIO(out.strip())))
-                    if len(rows) >= 2:
-                        samples.append((time.perf_counter(), dict(zip(rows[0], rows[-1]))))
-                except Exception as exc:      # an extra: never takes the benchmark down
-                    samples.append((time.perf_counter(), {"error": str(exc)}))
-                time.sleep(0.1)
+                d = {}
+                for key, fname, scale in fields:
+                    if key in d or not hw:
+                        continue
+                    try:
+                        with open(os.path.join(hw[0], fname)) as fh:
+                            d[key] = float(fh.read().strip()) * scale
+                    except (OSError, ValueError):
+                        pass
+                samples.append((time.perf_counter(), d))
+                time.sleep(0.02)
         th = threading.Thread(target=poll, daemon=True)
         th.start()
         time.sleep(0.3)                        # a few idle samples first
@@ -554,16 +562,12 @@ def main():
             cols = {}
             for _, d in window:
                 for k, v in d.items():
-                    try:
-                        x = float(str(v).strip("()MHhzWCmVc% "))
-                    except ValueError:
-                        continue
-                    cols.setdefault(k, []).append(x)
-            return {k: {"min": min(v), "median": float(np.median(v)), "max": max(v)} for k, v in cols.items() if k.lower() != "device"}
+                    cols.setdefault(k, []).append(float(v))
+            return {k: {"min": min(v), "median": float(np.median(v)), "max": max(v)} for k, v in cols.items()}
         under = [x for x in samples if t_start + 0.5 * (t_stop - t_start) <= x[0] <= t_stop]
         idle = [x for x in samples if x[0] < t_start]
         smi = numeric(under)
-        power = next((v["median"] for k, v in smi.items() if "power" in k.lower()), None)
+        power = smi.get("power_W", {}).get("median")
         for nb in big[len(batches):]:
             nb.close()
         return {"seconds": t_stop - t_start, "rounds": len(rounds), "batches_per_round": len(big),
@@ -572,8 +576,8 @@ def main():
                 "steady_newton_steps_per_s": spl / (ms_half * 1e-3),
                 "wall_clock_newton_steps_per_s_including_the_restarts": spl * len(big) * len(rounds) / (t_stop - t_start),
                 "joule_per_newton_step_at_median_power": (power / (spl / (ms_whole * 1e-3))) if power else None,
-                "rocm_smi_idle_before": numeric(idle), "rocm_smi_second_half_under_load": smi, "rocm_smi_samples": len(samples),
-                "rocm_smi_last_sample_raw": (under[-1][1] if under else None),
+                "hwmon_idle_before": numeric(idle), "hwmon_second_half_under_load": smi, "hwmon_samples": len(samples),
+                "hwmon_source": (hw[0] if hw else None),
                 "note": "per round every batch of a large pool is put back on its feasible start (k_restart_feasible, outside the events, ~8 % of the "
                         "round: the chip sees a short memory-bound breather there) and then all are solved back to back (k_solve_chunks, HIP events "
                         "around the solves only; the second half of each solve phase timed separately); steady = second halves of the later rounds"}
@@ -981,8 +985,12 @@ def main():
         line["cold_start"] = {"launches": min(K, n_batches), "ms_per_launch": cold_ms, "newton_steps_per_s": steps_per_launch / (cold_ms * 1e-3),
                               "note": "the K launches issued after 0.3 s of idling: inside the power controller's transient"}
 
-    if args.sustain_seconds > 0:
-        line["sustained"] = sustain(args.sustain_seconds)
+    sustain_s = args.sustain_seconds if args.sustain_seconds is not None else (1.5 if (world == 1 and not args.no_extras) else 0.0)
+    if sustain_s > 0:
+        try:
+            line["sustained"] = sustain(sustain_s)
+        except Exception as exc:      # an extra: never takes the benchmark down
+            line["sustained"] = {"error": str(exc)}
 
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(min(count, 1 << 19))
