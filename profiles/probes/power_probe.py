@@ -1,3 +1,5 @@
+"""Round 3's power probe.  SUPERSEDED by `bench.py --sustain-seconds S`, which reads the device's hwmon files instead of starting rocm-smi (a
+`#!/usr/bin/env python3` script) from a process that has initialised the GPU -- never run this one under rocprofv3."""
 import os, sys, time, subprocess, threading
 sys.path.insert(0, '/root/repo')
 import rocket_path_amd as rp
