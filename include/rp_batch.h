@@ -46,8 +46,10 @@ typedef struct rp_batch rp_batch; /* opaque, owned by the caller between create 
  *   3  round 3: sizeof(rp_params) returned by rp_params_size(); set_problems defers the feasible start
  *   4  round 4: rp_solution records (rp_batch_solution_device, rp_batch_bind_solution); rp_batch_traffic_probe replaces an
  *      environment switch; the library reads nothing from the environment; rp_batch_sample_device checks its alignment
- *   5  round 5: rp_device_id; a bound solution buffer is seeded before a gated launch that skips finished problems */
-#define RP_ABI_VERSION 5
+ *   5  round 5: rp_device_id; a bound solution buffer is seeded before a gated launch that skips finished problems
+ *   6  round 6: rp_pipeline_* (positions in -> solutions out over several streams); a raw pointer to a mutable field keeps the
+ *      seeding pass on for every later gated launch */
+#define RP_ABI_VERSION 6
 
 typedef enum {
     RP_OK = 0,
@@ -257,6 +259,44 @@ RP_API int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr);
  * init_default / init_stuck).  Every other entry point takes and returns problem order; only rp_batch_field_ptr
  * exposes batch order.  Synchronous. */
 RP_API int rp_batch_slot_map(rp_batch *b, uint32_t *slot_of_problem);
+
+/* ---- positions in -> solutions out, batch after batch (new: the reference solves ONE problem per key press, onedpath_ip.cpp:269-272;
+ * this is the caller either side of the batched path) ----
+ * A pipeline owns `depth` batches of n problems on one device and `n_streams` (1..4, depth a multiple of it) streams; job i goes to
+ * batch i % depth on stream (i % depth) % n_streams.  rp_pipeline_submit enqueues, for one job and without synchronising the host,
+ * exactly what a caller would issue by hand -- rp_batch_bind_solution, rp_batch_set_problems_device (the scheduling pass),
+ * rp_batch_solve (fused, from the feasible start formed in registers) -- so every result is bit for bit the one-stream path's.  What
+ * the arrangement buys: with n_streams >= 2 the scheduling pass of job i + 1 (memory- and latency-bound) and the first waves of its
+ * solve run under the drain of job i's solve (vector-ALU bound, wave slots emptying): "positions in, solutions out" at the rate of
+ * the solve kernel alone or better (bench.py `end_to_end`).
+ *   inputs_stream  the stream whose earlier work produces the position arrays (NULL: they are ready now); the job waits for it
+ *                  on the device.  The arrays must stay untouched until the job's scheduling pass has read them:
+ *                  rp_pipeline_stream_wait(job, 0, s) makes stream s wait for exactly that, rp_pipeline_wait(job) the host.
+ *   d_out          n rp_solution records in problem order (32-byte aligned; NULL: none -- read the batch through rp_pipeline_batch)
+ *   job            receives the job's number (0, 1, 2, ...); a slot is reused every `depth` jobs, in stream order -- the previous
+ *                  job of the slot has finished on the device before the new one touches the batch; its d_out is the caller's to
+ *                  have consumed by then. */
+typedef struct rp_pipeline rp_pipeline;
+RP_API int rp_pipeline_create(rp_pipeline **out, int variant, int dtype, size_t n, int device, int depth, int n_streams);
+RP_API int rp_pipeline_destroy(rp_pipeline *p);
+RP_API int rp_pipeline_set_params(rp_pipeline *p, const rp_params *params); /* every batch of the pipeline */
+/* Where the scheduling pass of a job runs (before the first submit only).  INLINE: on the job's own stream, ahead of its solve.
+ * STREAM / PRIORITY: on one more stream the pipeline owns (PRIORITY: created with the device's highest stream priority), ordered
+ * behind the slot's previous job and ahead of the job's solve by events -- so that it need not wait for a solve stream to run dry. */
+#define RP_PIPELINE_PREP_INLINE 0
+#define RP_PIPELINE_PREP_STREAM 1
+#define RP_PIPELINE_PREP_PRIORITY 2
+RP_API int rp_pipeline_set_prep(rp_pipeline *p, int mode);
+RP_API int rp_pipeline_submit(rp_pipeline *p, const double *d_pos0, const double *d_pos1, const double *d_pos2, rp_solution *d_out,
+                              double gap_tol, int max_iter, void *inputs_stream, int64_t *job);
+/* Host waits until job (and everything submitted to its slot before it) has finished; job < 0: everything submitted. */
+RP_API int rp_pipeline_wait(rp_pipeline *p, int64_t job);
+/* Device-side dependency: `stream` waits until the job's position arrays have been read (what = 0) or its solutions are
+ * written (what = 1).  Only while the job is still the last one of its slot. */
+RP_API int rp_pipeline_stream_wait(rp_pipeline *p, int64_t job, int what, void *stream);
+/* The batch that holds job (while it is still the last one of its slot): every rp_batch_* read-back works on it (rp_batch_reduce,
+ * rp_batch_get_iters, rp_batch_sample_device ...), on the job's own stream.  Owned by the pipeline. */
+RP_API int rp_pipeline_batch(rp_pipeline *p, int64_t job, rp_batch **batch);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""rp_pipeline arrangements (streams, where the scheduling pass runs) at steady clocks: ms per job of "positions in -> solutions out" at
+1 Mi problems, wall clock over a burst of jobs after a conditioning burst; the one-stream solve-only figure measured the same way beside it."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import rocket_path_amd as rp
+from hip_util import DeviceBuffer
+N = int(os.environ.get("N", 1 << 20)); JOBS = 120
+q = rp.problems.generate(12345, 0, N, 0)
+pos = DeviceBuffer(3 * 8 * N); pos.write(np.stack(q))
+outs = [DeviceBuffer(32 * N) for _ in range(4)]
+ptrs = (pos.ptr, pos.ptr + 8 * N, pos.ptr + 16 * N)
+
+def burst(pipe, jobs):
+    for j in range(jobs):
+        pipe.submit(*ptrs, d_out=outs[j % 4].ptr)
+    pipe.wait()
+
+res = {}
+for rnd in range(3):
+    for name, kw in (("1 stream, inline", dict(depth=2, n_streams=1)), ("2 streams, inline", dict(depth=4, n_streams=2)),
+                     ("2 streams, prep stream", dict(depth=4, n_streams=2, prep=1)), ("2 streams, prep high priority", dict(depth=4, n_streams=2, prep=2)),
+                     ("1 stream, prep high priority", dict(depth=2, n_streams=1, prep=2)), ("3 streams, prep high priority", dict(depth=6, n_streams=3, prep=2)),
+                     ("2 streams depth 8, prep high priority", dict(depth=8, n_streams=2, prep=2))):
+        with rp.Pipeline(N, **kw) as pipe:
+            burst(pipe, 160)                     # conditioning + first-use allocations
+            t = time.perf_counter(); burst(pipe, JOBS); dt = (time.perf_counter() - t) / JOBS * 1e3
+            tot = pipe.batch(JOBS + 160 - 1).reduce()["total_steps"]
+        res.setdefault(name, []).append(dt)
+        print("round %d  %-40s %.4f ms per job = %.2f G steps/s" % (rnd, name, dt, tot / dt / 1e6), flush=True)
+    # solve only, one stream and two (restart outside the clock is not possible in a burst: pre-armed batches)
+    for ns in (1, 2):
+        bs = [rp.Batch(N) for _ in range(ns)]
+        pool = bs + [rp.Batch(N, stream=bs[j % ns].stream()) for j in range(JOBS + 160 - ns)]
+        for b in pool:
+            b.set_problems_device(*ptrs); b.restart()
+        for b in bs: b.sync()
+        for b in pool[:160]: b.solve(1e-8, 200, 0)
+        t = time.perf_counter()
+        for b in pool[160:]: b.solve(1e-8, 200, 0)
+        for b in bs: b.sync()
+        dt = (time.perf_counter() - t) / JOBS * 1e3
+        print("round %d  %-40s %.4f ms per solve = %.2f G steps/s" % (rnd, "solve only, %d stream(s)" % ns, dt, tot / dt / 1e6), flush=True)
+        for b in pool[::-1]: b.close()
+print("best:", {k: round(min(v), 4) for k, v in res.items()})

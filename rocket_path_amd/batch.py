@@ -22,11 +22,15 @@ def _ptr(a):
 
 
 class Batch:
-    def __init__(self, n, variant=capi.VARIANT_F3, dtype=capi.DTYPE_F64, device=0, stream=None):
+    def __init__(self, n, variant=capi.VARIANT_F3, dtype=capi.DTYPE_F64, device=0, stream=None, _borrowed=None):
         self._lib = capi.load_library()
         self._h = ctypes.c_void_p()
-        capi.check(self._lib.rp_batch_create(ctypes.byref(self._h), variant, dtype, n, device,
-                                             ctypes.c_void_p(stream) if stream else None))
+        self._owned = _borrowed is None
+        if _borrowed is not None:          # a batch a pipeline owns (rp_pipeline_batch): every call works, close() leaves it alone
+            self._h = ctypes.c_void_p(_borrowed)
+        else:
+            capi.check(self._lib.rp_batch_create(ctypes.byref(self._h), variant, dtype, n, device,
+                                                 ctypes.c_void_p(stream) if stream else None))
         self.n, self.variant, self.dtype, self.device = n, variant, dtype, device
         self.state_len = 12 if variant == capi.VARIANT_F4 else 16
         self.num_constraints = 4 if variant == capi.VARIANT_F4 else 8
@@ -34,7 +38,8 @@ class Batch:
     # ---- lifetime ----
     def close(self):
         if self._h:
-            self._lib.rp_batch_destroy(self._h)
+            if self._owned:
+                self._lib.rp_batch_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):
@@ -205,3 +210,64 @@ class Batch:
         out = np.empty(self.n, dtype=np.uint32)
         capi.check(self._lib.rp_batch_slot_map(self._h, out.ctypes.data))
         return out
+
+
+class Pipeline:
+    """rp_pipeline: positions in -> solutions out, job after job, the batches dealt onto `n_streams` streams (include/rp_batch.h).
+    submit() enqueues one job (scheduling pass + fused gated solve, records into d_out in problem order) and returns its number."""
+
+    PREP_INLINE, PREP_STREAM, PREP_PRIORITY = 0, 1, 2      # RP_PIPELINE_PREP_*: where a job's scheduling pass runs
+
+    def __init__(self, n, variant=capi.VARIANT_F3, dtype=capi.DTYPE_F64, device=0, depth=4, n_streams=2, prep=None):
+        self._lib = capi.load_library()
+        self._h = ctypes.c_void_p()
+        capi.check(self._lib.rp_pipeline_create(ctypes.byref(self._h), variant, dtype, n, device, depth, n_streams))
+        self.n, self.variant, self.dtype, self.device, self.depth, self.n_streams = n, variant, dtype, device, depth, n_streams
+        if prep is not None:
+            capi.check(self._lib.rp_pipeline_set_prep(self._h, int(prep)))
+
+    def close(self):
+        if self._h:
+            self._lib.rp_pipeline_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_params(self, **kw):
+        p = capi.Params()
+        self._lib.rp_params_default(ctypes.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        capi.check(self._lib.rp_pipeline_set_params(self._h, ctypes.byref(p)))
+
+    def submit(self, d_pos0, d_pos1, d_pos2, d_out=None, gap_tol=1e-8, max_iter=200, inputs_stream=None):
+        job = ctypes.c_int64(-1)
+        capi.check(self._lib.rp_pipeline_submit(self._h, ctypes.c_void_p(d_pos0), ctypes.c_void_p(d_pos1), ctypes.c_void_p(d_pos2),
+                                                ctypes.c_void_p(d_out) if d_out else None, float(gap_tol), int(max_iter),
+                                                ctypes.c_void_p(inputs_stream) if inputs_stream else None, ctypes.byref(job)))
+        return job.value
+
+    def wait(self, job=-1):
+        capi.check(self._lib.rp_pipeline_wait(self._h, int(job)))
+
+    def stream_wait(self, job, what, stream):
+        """Make `stream` wait (on the device) until the job's positions have been read (what = 0) / its solutions are written (what = 1)."""
+        capi.check(self._lib.rp_pipeline_stream_wait(self._h, int(job), int(what), ctypes.c_void_p(stream)))
+
+    def batch(self, job):
+        """The batch that holds `job` (while it is the last job of its slot), as a Batch the pipeline keeps owning."""
+        h = ctypes.c_void_p()
+        capi.check(self._lib.rp_pipeline_batch(self._h, int(job), ctypes.byref(h)))
+        return Batch(self.n, self.variant, self.dtype, self.device, _borrowed=h.value)

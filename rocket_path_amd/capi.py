@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librp_batch.so")
 
 RP_OK = 0
-ABI_VERSION = 5      # RP_ABI_VERSION of include/rp_batch.h this binding was written against
+ABI_VERSION = 6      # RP_ABI_VERSION of include/rp_batch.h this binding was written against
 RP_ERR_INVALID, RP_ERR_DEVICE, RP_ERR_NOMEM, RP_ERR_UNSUPPORTED, RP_ERR_NO_DEVICE = 1, 2, 3, 4, 5
 VARIANT_F3, VARIANT_F4 = 3, 4
 DTYPE_F64, DTYPE_F32, DTYPE_F32_STATE = 0, 1, 2      # 2: fp32 state in HBM, fp64 arithmetic (include/rp_batch.h)
@@ -97,6 +97,14 @@ SIGNATURES = {
     "rp_batch_event_elapsed_ms": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
     "rp_batch_field_ptr": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_vp)]),
     "rp_batch_slot_map": (ctypes.c_int, [_vp, _vp]),
+    "rp_pipeline_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "rp_pipeline_destroy": (ctypes.c_int, [_vp]),
+    "rp_pipeline_set_params": (ctypes.c_int, [_vp, ctypes.POINTER(Params)]),
+    "rp_pipeline_set_prep": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "rp_pipeline_submit": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int64)]),
+    "rp_pipeline_wait": (ctypes.c_int, [_vp, ctypes.c_int64]),
+    "rp_pipeline_stream_wait": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp]),
+    "rp_pipeline_batch": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.POINTER(_vp)]),
 }
 
 _lib = None

@@ -1144,8 +1144,9 @@ __device__ __forceinline__ int skip_certain_halvings(const P &k, const KParams<T
 // reference's line search.  Fewer steps to the same optimum (measured: 15.4 -> 12.7 mean on the benchmark distribution);
 // each step costs more, and results are NOT the reference's iterates -- opt-in, off by default.
 // WAVE (ungated kernels whose lanes all take the same number of steps: every live lane of the wave is inside this function at
-// the same time): the residual loop's stragglers are served by the whole wave, see "wave-parallel line search" below.
-template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false>
+// the same time; the value is the instantiating kernel's block size and must be 64): the residual loop's stragglers are served by
+// the whole wave, see "wave-parallel line search" below.
+template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag, int WAVE = 0>
 __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp, T gap,
                                                const T v, const T t0, const T t1, const T (&lam)[CMap<VARIANT>::NC],
                                                const AccCarry<T, !MEMO, !MEMO && MU == 0> &c,
@@ -1275,8 +1276,12 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
     T tl[SUMS ? NC : 1];           // gated kernels: the trial multipliers lam + s dl of the last evaluated trial
     int it = 0;
     bool frozen = false;           // the trial point has become bitwise x (and stays so: s only shrinks)
-    if constexpr (WAVE && !SUMS) {
+    if constexpr (WAVE != 0 && !SUMS) {
         // ---- wave-parallel line search ----
+        // WAVE = the THREADS PER BLOCK of the kernel that instantiates this form (0: the serial search).  The service below broadcasts
+        // through one LDS area per block with no barrier, which is correct only in a single-wave block (a wave's LDS operations
+        // complete in order): any other launch shape fails to compile here.
+        static_assert(WAVE == 64, "newton_step_to<WAVE> broadcasts through LDS without a barrier: single-wave blocks (64 threads) only");
         // F4 never converges (README.md:34): from step ~6 a few per cent of the problems walk ~50 residual halvings at every
         // step, each with a full evaluation (the trial point still moves), while the other lanes of their wave have long
         // accepted -- per 64-lane wave 847 residual trials over 50 steps where a lane needs 21
@@ -1525,7 +1530,7 @@ __device__ __forceinline__ void newton_step_to(const P &k, const KParams<T> &kp,
 }
 
 // the same in place
-template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false>
+template <typename T, int VARIANT, class P, bool MEMO = true, bool AFFINE = false, int MU = 0, class D = NoDiag, int WAVE = 0>
 __device__ __forceinline__ void newton_step(const P &k, const KParams<T> &kp, T gap,
                                             T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC], AccCarry<T, !MEMO, !MEMO && MU == 0> &c,
                                             D &diag)

@@ -145,13 +145,20 @@ template <int VARIANT> constexpr bool kAffine = (VARIANT == 4);
 template <int VARIANT, bool GATED, int MU, class D>
 constexpr bool kStepInPlace = RP_GATED_IN_PLACE && MU == 0 && (GATED ? std::is_same<D, NoDiag>::value : VARIANT == 3);
 
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, class D = NoDiag, bool WAVE = false,
-          class BK = LdsColumn<T>>
+// PARK (RP_PARK_FIXED_POINTS; F4's fused fixed-step launches on an fp32 state with fp64 arithmetic): a lane whose step has left its STORED
+// state bit for bit where it was sits the remaining steps of the launch out -- see the ungated loop below.  (Pure fp32 arithmetic keeps
+// the plain loop: there the stuck problems are few -- its Armijo test stops resolving long before a state freezes -- and the bookkeeping
+// cost more than it saved: 50.0 against 53.8 G steps/s at 1 Mi x 50, profiles/r6_f4_park_ab.log.  The code below still handles S == T.)
+#ifndef RP_PARK_FIXED_POINTS
+#define RP_PARK_FIXED_POINTS 1      // 0: every lane takes every step (A/B builds: no bit may change)
+#endif
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, class D = NoDiag, int WAVE = 0,
+          class BK = LdsColumn<T>, bool PARK = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open, D &diag, BK backup = BK{})
 {
-    static_assert(!(WAVE && GATED), "lanes of a gated solve leave the loop at different steps");
+    static_assert(!(WAVE != 0 && GATED), "lanes of a gated solve leave the loop at different steps");
     constexpr bool INPLACE = kStepInPlace<VARIANT, GATED, MU, D>;
     // gated kernels carry the time derivatives as well (newton_step's MEMO = !GATED) and, in the reference's mu mode, the
     // residual sums, from which the gap of the current point comes for free; so does every launch that steps in place
@@ -240,6 +247,62 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
             }
             if (__builtin_amdgcn_ballot_w64(open) == 0ull) break;
         }
+    } else if constexpr (PARK && RP_PARK_FIXED_POINTS != 0) {
+        // ---- fixed points sit out (exact) ----
+        // F4 never converges (README.md:34): from step ~6 on a growing share of its problems -- 2.4 % by step 48 on the benchmark
+        // distribution -- is STUCK: the residual loop (onedpath2_ip.cpp:820-833) halves the step ~52 times until x + s dx is x bit for
+        // bit and the multipliers move by less than an ulp of their fp32 storage, so the step stores the state it loaded.  The step is
+        // a function of the stored state (and of the evaluation carried with it, which is a function of the state as well): a
+        // state it maps onto itself it maps onto itself for ever, and every further step of the launch is the same ~52-halving
+        // walk to the same bits -- the lanes the wave-parallel line search exists for.  Such a lane is parked: it takes no further
+        // steps in this launch, and what it stores is bit for bit what the steps would have left (tests/checks/fixed_step_ab.py
+        // against a build with RP_PARK_FIXED_POINTS=0; measured on the oracle, profiles/r6_tuning.md: the stuck problems and the
+        // fixed points of the fp32-state step are the same problems, none ever leaves).  Bit patterns are compared, not values
+        // (-0 against +0 is a change, NaN against the same NaN is none), and with S == T (no re-evaluation after the step) the
+        // carried evaluation is compared too.  A wave whose lanes are all parked leaves the loop.
+        static_assert(!INPLACE && MU == 0 && !GATED && sizeof(S) == 4, "parking is built on newton_step_to's separate outputs, for states stored in fp32");
+        constexpr int NCc = CMap<VARIANT>::NC;
+        auto bits = [](T x) { if constexpr (sizeof(T) == 8) return __builtin_bit_cast(unsigned long long, x); else return __builtin_bit_cast(unsigned, x); };
+        bool parked = false;
+        for (int s = 0; s < k; ++s) {
+            if (__builtin_amdgcn_ballot_w64(!parked) == 0ull) { steps_here += k - s; break; }
+            if (!parked) {
+                const T gap = current_gap();
+                T nv, nt0, nt1, nlam[NCc];
+                Carry ne;
+                // (the problem's two deltas made opaque once per step: otherwise the compiler hoists every loop-invariant function of them the
+                // proofs use -- 6 dX, its negation, its magnitude, the margins: seven register pairs -- out of the step loop, and the
+                // fp32-state instantiation, 166 of the 168 VGPRs three waves allow, spills; recomputing them is six instructions per step)
+                P pq = pr;
+                if constexpr (sizeof(T) == 8) asm volatile("" : "+v"(pq.dx0), "+v"(pq.dx1));
+                newton_step_to<T, VARIANT, P, true, AFFINE, MU, D, WAVE>(pq, kp, gap, v, t0, t1, lam, e, nv, nt0, nt1, nlam, ne, diag);
+                // value by value: round to the storage type, compare with what is stored, take it (one value in flight at a time: the
+                // kernel has no registers to hold two states side by side)
+                bool same = true;
+                auto take = [&](T &cur, T nxt) {
+                    if constexpr (sizeof(S) != sizeof(T)) {
+                        const S r = (S)nxt;
+                        same = same && __builtin_bit_cast(unsigned, r) == __builtin_bit_cast(unsigned, (S)cur);      // (cur holds a value of S exactly)
+                        cur = (T)r;
+                    } else {
+                        same = same && bits(nxt) == bits(cur);
+                        cur = nxt;
+                    }
+                };
+                take(v, nv); take(t0, nt0); take(t1, nt1);
+#pragma unroll
+                for (int c = 0; c < NCc; ++c) take(lam[c], nlam[c]);
+                if constexpr (sizeof(S) == sizeof(T)) {      // (otherwise evaluate() below rebuilds the carried evaluation from the rounded state: a function of it)
+                    same = same && bits(ne.r0) == bits(e.r0) && bits(ne.r1) == bits(e.r1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) same = same && bits(ne.a[j]) == bits(e.a[j]);
+                }
+                parked = same;
+                if constexpr (sizeof(S) != sizeof(T)) evaluate();      // the carried evaluation belongs to the unrounded point
+                else e = ne;
+            }
+            ++steps_here;
+        }
     } else
     for (int s = 0; s < k; ++s) {
         const T gap = current_gap();
@@ -285,13 +348,13 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
 }
 
 // the common call: no line-search bookkeeping
-template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, bool WAVE = false>
+template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, int WAVE = 0, bool PARK = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open, LdsColumn<T> backup = LdsColumn<T>{})
 {
     NoDiag none;
-    run_lane<T, VARIANT, GATED, STALL, P, S, AFFINE, MU, NoDiag, WAVE>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open, none, backup);
+    run_lane<T, VARIANT, GATED, STALL, P, S, AFFINE, MU, NoDiag, WAVE, LdsColumn<T>, PARK>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it, st, steps_here, still_open, none, backup);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -537,8 +600,9 @@ k_steps_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
     } else {
     // F4 has the registers for the affine post-convergence loop (and reaches "the trial point is x" within a dozen steps:
     // its stalled problems), so all its fixed-step kernels use it and agree bit for bit
-    static_assert(kChunkBlock == 64, "newton_step_to<WAVE> broadcasts through LDS without a barrier: single-wave blocks only");
-    run_lane<T, VARIANT, false, false, Pk, S, kAffine<VARIANT>, 0, RP_WAVE_LS && (VARIANT == 4)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
+    // (newton_step_to<WAVE> broadcasts through LDS without a barrier: single-wave blocks only -- the block size travels into the step as
+    // the template argument WAVE and is asserted THERE, inside the WAVE branch, so that no multi-wave kernel can instantiate it: ADVICE r5)
+    run_lane<T, VARIANT, false, false, Pk, S, kAffine<VARIANT>, 0, (RP_WAVE_LS && VARIANT == 4) ? kChunkBlock : 0, (VARIANT == 4 && sizeof(S) == 4 && sizeof(T) == 8)>(pr, kp, k, T(0), 0, v, t0, t1, lam, it, st, steps_here, still_open);
     }
     // the store addresses are formed only now: the barrier keeps the compiler from holding eleven of them in registers
     // across the steps (168 VGPRs and 4-10 spilled without it, 152 with it)
@@ -1317,7 +1381,9 @@ hipError_t launch_steps(const BatchView &b, const HostParams &hp, int k, hipStre
         if (b.variant == 3 && b.n <= reg_column_upto) {
             constexpr int V3 = 3;
 #ifdef RP_TUNING
-            static const unsigned lanes = getenv("RP_LANES_PER_WAVE") ? (unsigned)atoi(getenv("RP_LANES_PER_WAVE")) : 64u;      // A/B: part-filled waves
+            static const unsigned lanes_env = getenv("RP_LANES_PER_WAVE") ? (unsigned)atoi(getenv("RP_LANES_PER_WAVE")) : 64u;      // A/B: part-filled waves
+            if (lanes_env < 1u || lanes_env > 64u) return hipErrorInvalidValue;      // (0 would divide by zero below, > 64 would leave problems unprocessed: ADVICE r5)
+            const unsigned lanes = lanes_env;
 #else
             constexpr unsigned lanes = 64u;
 #endif

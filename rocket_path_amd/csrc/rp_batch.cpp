@@ -39,6 +39,10 @@ struct rp_batch {
                               // for the life of the batch
     bool sol_stale;           // a solution buffer is bound and something other than a gated solve has touched the state (or the buffer is new): the
                               // records of problems the next gated launch does NOT work on are not current -- that launch seeds the buffer first
+    bool raw_state_out;       // a raw pointer to a MUTABLE field (vel1, a duration, a multiplier) has been handed out (rp_batch_field_ptr): the caller
+                              // may write state the batch never sees, at any later time -- sticky until the next init / set_problems / set_state
+                              // (which invalidate such pointers' meaning): while it is set, a bound solution buffer is seeded before EVERY gated
+                              // launch that may skip problems, not only the first one after the hand-out
     bool at_start;            // set_problems has run and nothing else since: the batch holds its scheduled order and its positions; the
                               // feasible start itself (mutable fields, progress words) is NOT materialised yet -- see materialize()
     double ungated_steps;     // per-problem count of ungated steps since the last init
@@ -140,10 +144,9 @@ int materialize(rp_batch *b)
 // stores every record itself.
 int seed_solution(rp_batch *b)
 {
-    if (!b->view.solution || !b->sol_stale) return RP_OK;
+    if (!b->view.solution || !(b->sol_stale || b->raw_state_out)) return RP_OK;
     RP_HIP(rp::launch_solution(b->view, b->view.solution, b->stream));
-    b->sol_stale = false;
-    return RP_OK;
+    return RP_OK;      // (sol_stale is cleared by the caller once its gated launch has been enqueued: a failed launch leaves the buffer stale)
 }
 
 #define RP_NEED_STATE(b)                     \
@@ -182,7 +185,7 @@ int need_aos(rp_batch *b)
 
 extern "C" {
 
-const char *rp_version(void) { return "rocket_path_amd 0.5 (gfx950)"; }
+const char *rp_version(void) { return "rocket_path_amd 0.6 (gfx950)"; }
 int rp_abi_version(void) { return RP_ABI_VERSION; }
 size_t rp_params_size(void) { return sizeof(rp_params); }
 const char *rp_last_error(void) { return g_err; }
@@ -409,6 +412,7 @@ int rp_batch_init_default(rp_batch *b)
     s[3 + m + 0] = 0.0; s[3 + m + 1] = 0.0; s[3 + m + 2] = 200.0; s[3 + m + 3] = 400.0; s[3 + m + 4] = 0.0;
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
     b->sol_stale = true;
+    b->raw_state_out = false;
     b->view.zero_end_vel = true;
     b->view.scheduled = false;         // identical problems: nothing to schedule
     b->at_start = false;
@@ -426,6 +430,7 @@ int rp_batch_init_stuck(rp_batch *b)
                           0.0, 0.0, 350.0, 400.0, 0.0};
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
     b->sol_stale = true;
+    b->raw_state_out = false;
     b->view.zero_end_vel = true;
     b->view.scheduled = false;
     b->at_start = false;
@@ -450,6 +455,7 @@ int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double
     b->view.zero_end_vel = true;       // the feasible-start rule sets vel0 = vel2 = 0
     b->ungated_steps = 0.0;
     b->sol_stale = true;
+    b->raw_state_out = false;
     b->at_start = true;
     b->records_current = true;
     return RP_OK;
@@ -503,6 +509,7 @@ int rp_batch_set_state(rp_batch *b, const double *aos)
         b->at_start = false;      // the rows below are the state
         b->records_current = false;
         b->sol_stale = true;
+        b->raw_state_out = false;
     }
     RP_HIP(rp::launch_aos_to_soa(b->view, b->d_aos, b->stream));
     st = reset_progress(b);
@@ -611,8 +618,8 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
         else { const int ms = materialize(b); if (ms != RP_OK) return ms; }
         b->view.iters_add = (int)b->ungated_steps;
         if (!from_start) { const int ss = seed_solution(b); if (ss != RP_OK) return ss; }      // (the START launch stores every record itself)
-        b->sol_stale = false;
         RP_HIP(rp::launch_solve_fused(b->view, b->params, gap_tol, max_iter, from_start, b->stream));
+        b->sol_stale = false;      // only now: a launch that failed has written no record
         return RP_OK;
     }
     { const int ms = materialize(b); if (ms != RP_OK) return ms; }
@@ -622,6 +629,7 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
     const int max_launches = max_iter / steps_per_launch + 2;
     for (int l = 0; l < max_launches; ++l) {
         RP_HIP(rp::launch_solve(b->view, b->params, steps_per_launch, gap_tol, max_iter, b->stream));
+        b->sol_stale = false;
         RP_HIP(hipMemcpyAsync(b->h_pinned, b->view.counters, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
         RP_HIP(hipStreamSynchronize(b->stream));
         unsigned long long open = 0;
@@ -640,6 +648,7 @@ int rp_batch_solve_launch(rp_batch *b, double gap_tol, int max_iter, int k)
     b->view.iters_add = (int)b->ungated_steps;
     { const int ss = seed_solution(b); if (ss != RP_OK) return ss; }
     RP_HIP(rp::launch_solve(b->view, b->params, k, gap_tol, max_iter, b->stream));
+    b->sol_stale = false;
     return RP_OK;
 }
 
@@ -857,6 +866,7 @@ int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr)
     b->records_current = false;      // the caller may write through the pointer
     b->sol_stale = true;
     if (field >= 3 + rp::num_constraints(b->view.variant)) b->raw_positions_out = true;      // ... now or at any later time: sticky (see the struct)
+    else b->raw_state_out = true;                                                            // ... and so may the state: every later gated launch seeds a bound buffer first
     {   // a caller holding a raw pointer to an end-velocity field may write non-zero values the batch never sees: from
         // here on (until the next init / set_problems / set_state) the Newton kernels read vel0X and vel2X
         const int iv0 = 3 + rp::num_constraints(b->view.variant) + 1, iv2 = iv0 + 3;
@@ -876,6 +886,196 @@ int rp_batch_slot_map(rp_batch *b, uint32_t *slot_of_problem)
     }
     RP_HIP(hipMemcpyAsync(slot_of_problem, b->view.slot_of, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     RP_HIP(hipStreamSynchronize(b->stream));
+    return RP_OK;
+}
+
+// ---- rp_pipeline: positions in -> solutions out, batch after batch, with the batches dealt onto several streams ----
+// Nothing but the entry points above, in the order a caller would issue them by hand: what it adds is the arrangement -- `depth` batches
+// of n problems, slot j bound to stream j % n_streams at creation, job i in slot i % depth -- under which the scheduling pass of job
+// i + 1 (three small memory- and latency-bound kernels) and the head of its solve run while job i's solve, a vector-ALU-bound kernel on
+// the other stream, is still draining: wave slots stand empty 18 % of a lone 1 Mi-problem launch at its two ends (profiles/r5_tuning.md).
+}  // extern "C"
+
+struct rp_pipeline {
+    int device, depth, n_streams;
+    size_t n;
+    hipStream_t streams[4];
+    rp_batch **slots;
+    hipEvent_t *done;          // per slot: recorded behind the slot's last job
+    hipEvent_t *consumed;      // per slot: recorded behind that job's scheduling pass (its position arrays have been read)
+    hipEvent_t inputs_ready;   // scratch: recorded on the caller's stream in rp_pipeline_submit
+    hipStream_t prep;          // prep_mode != 0: the stream every job's scheduling pass runs on (its solve waits for it through `consumed`)
+    int prep_mode;             // RP_PIPELINE_PREP_*
+    int64_t *job_of;           // per slot: the job it last took (-1: none)
+    int64_t next_job;
+};
+
+extern "C" {
+
+int rp_pipeline_create(rp_pipeline **out, int variant, int dtype, size_t n, int device, int depth, int n_streams)
+{
+    if (!out) return fail(RP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (n_streams < 1 || n_streams > 4) return fail(RP_ERR_INVALID, "n_streams %d (want 1..4)", n_streams);
+    if (depth < n_streams || depth > 1024 || depth % n_streams != 0)
+        return fail(RP_ERR_INVALID, "depth %d (want a multiple of n_streams = %d, at most 1024)", depth, n_streams);
+    rp_pipeline *p = new (std::nothrow) rp_pipeline();
+    if (!p) return fail(RP_ERR_NOMEM, "host allocation failed");
+    std::memset(p, 0, sizeof *p);
+    p->device = device; p->depth = depth; p->n_streams = n_streams; p->n = n;
+    p->slots = new (std::nothrow) rp_batch *[depth]();
+    p->done = new (std::nothrow) hipEvent_t[depth]();
+    p->consumed = new (std::nothrow) hipEvent_t[depth]();
+    p->job_of = new (std::nothrow) int64_t[depth]();
+    if (!p->slots || !p->done || !p->consumed || !p->job_of) { rp_pipeline_destroy(p); return fail(RP_ERR_NOMEM, "host allocation failed"); }
+    for (int j = 0; j < depth; ++j) p->job_of[j] = -1;
+    int st = RP_OK;
+    for (int j = 0; j < depth && st == RP_OK; ++j) {
+        // the first batch of a stream creates it (a non-blocking stream of its own); the others of that stream share it
+        st = rp_batch_create(&p->slots[j], variant, dtype, n, device, j < n_streams ? nullptr : (void *)p->streams[j % n_streams]);
+        if (st == RP_OK && j < n_streams) p->streams[j] = p->slots[j]->stream;
+        if (st == RP_OK && hipEventCreateWithFlags(&p->done[j], hipEventDisableTiming) != hipSuccess) st = fail(RP_ERR_DEVICE, "hipEventCreate failed");
+        if (st == RP_OK && hipEventCreateWithFlags(&p->consumed[j], hipEventDisableTiming) != hipSuccess) st = fail(RP_ERR_DEVICE, "hipEventCreate failed");
+    }
+    if (st == RP_OK && hipEventCreateWithFlags(&p->inputs_ready, hipEventDisableTiming) != hipSuccess) st = fail(RP_ERR_DEVICE, "hipEventCreate failed");
+    if (st != RP_OK) {
+        char keep[sizeof g_err];
+        std::memcpy(keep, g_err, sizeof keep);
+        rp_pipeline_destroy(p);
+        std::memcpy(g_err, keep, sizeof keep);
+        return st;
+    }
+    *out = p;
+    return RP_OK;
+}
+
+int rp_pipeline_destroy(rp_pipeline *p)
+{
+    if (!p) return RP_OK;
+    (void)hipSetDevice(p->device);
+    if (p->slots) {
+        // batches that share a stream must go before the batch that owns it (slot j < n_streams owns stream j)
+        for (int j = p->depth - 1; j >= 0; --j) if (p->slots[j]) rp_batch_destroy(p->slots[j]);
+    }
+    for (int j = 0; j < p->depth; ++j) {
+        if (p->done && p->done[j]) (void)hipEventDestroy(p->done[j]);
+        if (p->consumed && p->consumed[j]) (void)hipEventDestroy(p->consumed[j]);
+    }
+    if (p->inputs_ready) (void)hipEventDestroy(p->inputs_ready);
+    if (p->prep) { (void)hipStreamSynchronize(p->prep); (void)hipStreamDestroy(p->prep); }
+    delete[] p->slots;
+    delete[] p->done;
+    delete[] p->consumed;
+    delete[] p->job_of;
+    delete p;
+    return RP_OK;
+}
+
+int rp_pipeline_set_prep(rp_pipeline *p, int mode)
+{
+    if (!p) return fail(RP_ERR_INVALID, "null pipeline handle");
+    if (mode != RP_PIPELINE_PREP_INLINE && mode != RP_PIPELINE_PREP_STREAM && mode != RP_PIPELINE_PREP_PRIORITY)
+        return fail(RP_ERR_INVALID, "prep mode %d (want 0 = on the job's stream, 1 = a stream of its own, 2 = ... with the highest priority)", mode);
+    if (p->next_job != 0) return fail(RP_ERR_INVALID, "the arrangement is fixed once a job has been submitted");
+    RP_HIP(hipSetDevice(p->device));
+    if (p->prep) { (void)hipStreamDestroy(p->prep); p->prep = nullptr; }
+    p->prep_mode = mode;
+    if (mode == RP_PIPELINE_PREP_INLINE) return RP_OK;
+    int least = 0, greatest = 0;
+    if (mode == RP_PIPELINE_PREP_PRIORITY) RP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    RP_HIP(hipStreamCreateWithPriority(&p->prep, hipStreamNonBlocking, mode == RP_PIPELINE_PREP_PRIORITY ? greatest : 0));
+    return RP_OK;
+}
+
+int rp_pipeline_set_params(rp_pipeline *p, const rp_params *params)
+{
+    if (!p || !params) return fail(RP_ERR_INVALID, "null argument");
+    for (int j = 0; j < p->depth; ++j) {
+        const int st = rp_batch_set_params(p->slots[j], params);
+        if (st != RP_OK) return st;
+    }
+    return RP_OK;
+}
+
+int rp_pipeline_submit(rp_pipeline *p, const double *d_pos0, const double *d_pos1, const double *d_pos2, rp_solution *d_out,
+                       double gap_tol, int max_iter, void *inputs_stream, int64_t *job)
+{
+    if (!p) return fail(RP_ERR_INVALID, "null pipeline handle");
+    RP_HIP(hipSetDevice(p->device));
+    const int64_t id = p->next_job;
+    const int slot = (int)(id % p->depth);
+    rp_batch *b = p->slots[slot];
+    // The scheduling pass runs on the job's own stream or -- prep_mode -- on the pipeline's prep stream, behind the slot's previous job
+    // (it overwrites the batch's order and records) and ahead of this job's solve (which waits for `consumed`).
+    hipStream_t solve_stream = b->stream, sched_stream = p->prep ? p->prep : b->stream;
+    if (inputs_stream && (hipStream_t)inputs_stream != sched_stream) {      // the positions are produced by work on the caller's stream: wait for it, on the device
+        RP_HIP(hipEventRecord(p->inputs_ready, (hipStream_t)inputs_stream));
+        RP_HIP(hipStreamWaitEvent(sched_stream, p->inputs_ready, 0));
+    }
+    int st = rp_batch_bind_solution(b, d_out);
+    if (st != RP_OK) return st;
+    if (p->prep) {
+        if (p->job_of[slot] >= 0) RP_HIP(hipStreamWaitEvent(p->prep, p->done[slot], 0));
+        b->stream = p->prep;
+        st = rp_batch_set_problems_device(b, d_pos0, d_pos1, d_pos2);
+        b->stream = solve_stream;
+    } else {
+        st = rp_batch_set_problems_device(b, d_pos0, d_pos1, d_pos2);
+    }
+    if (st != RP_OK) return st;
+    RP_HIP(hipEventRecord(p->consumed[slot], sched_stream));
+    if (p->prep) RP_HIP(hipStreamWaitEvent(solve_stream, p->consumed[slot], 0));
+    st = rp_batch_solve(b, gap_tol, max_iter, 0);
+    if (st != RP_OK) return st;
+    RP_HIP(hipEventRecord(p->done[slot], b->stream));
+    p->job_of[slot] = id;
+    p->next_job = id + 1;
+    if (job) *job = id;
+    return RP_OK;
+}
+
+static int pipeline_slot_of(rp_pipeline *p, int64_t job, int *slot)
+{
+    if (!p) return fail(RP_ERR_INVALID, "null pipeline handle");
+    if (job < 0 || job >= p->next_job) return fail(RP_ERR_INVALID, "job %lld has not been submitted", (long long)job);
+    *slot = (int)(job % p->depth);
+    if (p->job_of[*slot] != job) return fail(RP_ERR_INVALID, "job %lld has left the pipeline: its slot holds job %lld", (long long)job, (long long)p->job_of[*slot]);
+    return RP_OK;
+}
+
+int rp_pipeline_wait(rp_pipeline *p, int64_t job)
+{
+    if (!p) return fail(RP_ERR_INVALID, "null pipeline handle");
+    RP_HIP(hipSetDevice(p->device));
+    if (job < 0) {      // everything submitted so far
+        if (p->prep) RP_HIP(hipStreamSynchronize(p->prep));      // (first: a solve stream's last solve waits on it)
+        for (int j = 0; j < p->n_streams; ++j) RP_HIP(hipStreamSynchronize(p->streams[j]));
+        return RP_OK;
+    }
+    if (job >= p->next_job) return fail(RP_ERR_INVALID, "job %lld has not been submitted", (long long)job);
+    const int slot = (int)(job % p->depth);
+    RP_HIP(hipEventSynchronize(p->done[slot]));      // (the slot's LAST job: a later job of the same slot follows the asked one on one stream)
+    return RP_OK;
+}
+
+int rp_pipeline_stream_wait(rp_pipeline *p, int64_t job, int what, void *stream)
+{
+    int slot = 0;
+    const int st = pipeline_slot_of(p, job, &slot);
+    if (st != RP_OK) return st;
+    if (what != 0 && what != 1) return fail(RP_ERR_INVALID, "what = %d (0: the job's positions have been read, 1: its solutions are written)", what);
+    RP_HIP(hipSetDevice(p->device));
+    RP_HIP(hipStreamWaitEvent((hipStream_t)stream, what == 0 ? p->consumed[slot] : p->done[slot], 0));
+    return RP_OK;
+}
+
+int rp_pipeline_batch(rp_pipeline *p, int64_t job, rp_batch **batch)
+{
+    if (!batch) return fail(RP_ERR_INVALID, "null output");
+    int slot = 0;
+    const int st = pipeline_slot_of(p, job, &slot);
+    if (st != RP_OK) return st;
+    *batch = p->slots[slot];
     return RP_OK;
 }
 

@@ -74,6 +74,30 @@ def test_invalid_arguments_are_rejected_without_a_device():
             rp.device_id(0)
 
 
+def test_pipeline_arguments_are_checked_without_a_device():
+    # rp_pipeline (ABI revision 6): the arrangement is checked before any device is asked; without a device creation fails as
+    # rp_batch_create does (no CPU fallback), and null handles are refused
+    lib = capi.load_library()
+    h = ctypes.c_void_p()
+    assert lib.rp_pipeline_create(None, 3, 0, 64, 0, 4, 2) == capi.RP_ERR_INVALID
+    assert lib.rp_pipeline_create(ctypes.byref(h), 3, 0, 64, 0, 4, 0) == capi.RP_ERR_INVALID and b"n_streams" in lib.rp_last_error()
+    assert lib.rp_pipeline_create(ctypes.byref(h), 3, 0, 64, 0, 4, 5) == capi.RP_ERR_INVALID
+    assert lib.rp_pipeline_create(ctypes.byref(h), 3, 0, 64, 0, 3, 2) == capi.RP_ERR_INVALID and b"multiple" in lib.rp_last_error()
+    assert lib.rp_pipeline_create(ctypes.byref(h), 3, 0, 64, 0, 1, 2) == capi.RP_ERR_INVALID
+    assert h.value is None
+    job = ctypes.c_int64()
+    assert lib.rp_pipeline_submit(None, None, None, None, None, 1e-8, 200, None, ctypes.byref(job)) == capi.RP_ERR_INVALID
+    assert lib.rp_pipeline_wait(None, -1) == capi.RP_ERR_INVALID
+    assert lib.rp_pipeline_stream_wait(None, 0, 0, None) == capi.RP_ERR_INVALID
+    assert lib.rp_pipeline_batch(None, 0, ctypes.byref(h)) == capi.RP_ERR_INVALID
+    assert lib.rp_pipeline_destroy(None) == capi.RP_OK
+    if rp.device_count() == 0:
+        assert lib.rp_pipeline_create(ctypes.byref(h), 3, 0, 64, 0, 4, 2) == capi.RP_ERR_NO_DEVICE and h.value is None
+        with pytest.raises(rp.RpError) as e:
+            rp.Pipeline(64)
+        assert e.value.status == capi.RP_ERR_NO_DEVICE
+
+
 @pytest.mark.skipif(rp.device_count() > 0, reason="a GPU is present: the no-device path cannot be exercised")
 def test_no_device_means_loud_failure_not_a_cpu_fallback():
     with pytest.raises(rp.RpError) as e:

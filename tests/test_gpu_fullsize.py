@@ -93,27 +93,41 @@ def test_config5_f4_fp32_one_million_runs_and_stays_finite():
 
 
 def test_config5_f4_fp32_state_one_million_one_step_against_the_fp64_oracle(oracle):
-    # config 5 at full size, per-problem bound: after 10 steps of the 1 Mi batch (fp32 state, fp64 arithmetic) take one
-    # more step and compare a 64k slice with the fp64 oracle stepping from the identical (fp32-representable) states
+    # config 5 at full size, per-problem bound over the WHOLE batch (rounds 2-5 compared a 65,536 slice): after
+    # 10 steps of the 1 Mi batch (fp32 state, fp64 arithmetic) take one more step and compare all 1,048,576 problems with the fp64
+    # oracle stepping from the identical (fp32-representable) states -- and again from the state 30 more steps leave, where F4's
+    # long halving sequences and its stuck problems are there (the oracle steps 1 Mi F4 problems in a few seconds on the host's threads)
     n = 1 << 20
     p0, p1, p2 = rp.problems.generate(12345, 0, n, rp.problems.DIST_MONOTONE)
-    sl = slice(300000, 300000 + 65536)
+    worst = []
     with rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32_STATE) as b:
         b.set_problems(p0, p1, p2)
-        b.step(10)
-        before = b.get_state_range(sl.start, 65536)
-        b.step(1)
-        after = b.get_state_range(sl.start, 65536)
-        b.step(39)
+        done = 0
+        for upto in (10, 41):
+            b.step(upto - done)
+            before = b.get_state()
+            b.step(1)
+            after = b.get_state()
+            done = upto + 1
+            assert np.array_equal(before, before.astype(np.float32).astype(np.float64))
+            exp = before.copy()
+            oracle.batch_steps(4, exp, 1, threads=0)
+            err = np.abs(after[:, :3] - exp[:, :3]) / np.maximum(np.abs(exp[:, :3]), 1.0)
+            scale = np.max(np.abs(exp[:, 3:7]), axis=1, keepdims=True)
+            lerr = np.abs(after[:, 3:7] - exp[:, 3:7]) / scale
+            worst.append((upto + 1, float(err.max()), float(lerr.max()), int((err.max(axis=1) > 1.0e-7).sum()), int(np.all(after == before, axis=1).sum())))
+            # SURVEY C5 asks for ~1e-5 per problem.  Ten steps in, every one of the 1,048,576 problems is within fp32 rounding (1e-7, the bound
+            # the 4,096 golden states meet); 41 steps in, F4's problems sit in 12-21-halving sequences whose last trial is a tie for a few of a
+            # million of them (the device's reciprocal against the reference's divisions: one more halving of a step of ~1e-6): 1e-6 there,
+            # with the number of problems beyond 1e-7 printed
+            tol = 1.0e-7 if upto == 10 else 1.0e-6
+            assert err.max() < tol, (upto, err.max())
+            assert lerr.max() < 10 * tol, (upto, lerr.max())
+        b.step(50 - done)
         st = b.get_state()
         pos, acc = b.sample_range(0, 1 << 16)
-    assert np.array_equal(before, before.astype(np.float32).astype(np.float64))
-    exp = before.copy()
-    oracle.batch_steps(4, exp, 1)
-    err = np.abs(after[:, :3] - exp[:, :3]) / np.maximum(np.abs(exp[:, :3]), 1.0)
-    assert err.max() < 1.0e-7, err.max()
-    scale = np.max(np.abs(exp[:, 3:7]), axis=1, keepdims=True)
-    assert np.max(np.abs(after[:, 3:7] - exp[:, 3:7]) / scale) < 1.0e-7
+    print("configs[4], fp32 state + fp64 arithmetic, all 1,048,576 problems against the fp64 oracle, one step from identical states: " +
+          "; ".join("step %d: worst (v, t0, t1) %.2e, multipliers %.2e, %d problems beyond 1e-7, %d left bit for bit unchanged" % w for w in worst))
     assert np.all(np.isfinite(st)) and np.all(st[:, 1] > 0) and np.all(st[:, 2] > 0)
     assert np.max(np.abs(acc)) <= 100.0 * (1 + 1e-6)      # feasible up to the rounding of the state to fp32
 
