@@ -280,12 +280,15 @@ typedef struct rp_pipeline rp_pipeline;
 RP_API int rp_pipeline_create(rp_pipeline **out, int variant, int dtype, size_t n, int device, int depth, int n_streams);
 RP_API int rp_pipeline_destroy(rp_pipeline *p);
 RP_API int rp_pipeline_set_params(rp_pipeline *p, const rp_params *params); /* every batch of the pipeline */
-/* Where the scheduling pass of a job runs (before the first submit only).  INLINE: on the job's own stream, ahead of its solve.
- * STREAM / PRIORITY: on one more stream the pipeline owns (PRIORITY: created with the device's highest stream priority), ordered
- * behind the slot's previous job and ahead of the job's solve by events -- so that it need not wait for a solve stream to run dry. */
+/* Where the scheduling pass of a job runs (before the first submit only).  INLINE (the default): on the job's own stream, ahead of its
+ * solve.  STREAM / PRIORITY: on one more stream the pipeline owns (PRIORITY: created with the device's highest stream priority), ordered
+ * behind the slot's previous job and ahead of the job's solve by events.  Measured equal to INLINE within 1 % where the process owns few
+ * streams; every further stream risks sharing a hardware queue with another (the HIP runtime has GPU_MAX_HW_QUEUES = 4 of them by
+ * default), and streams that share a queue serialise. */
 #define RP_PIPELINE_PREP_INLINE 0
 #define RP_PIPELINE_PREP_STREAM 1
 #define RP_PIPELINE_PREP_PRIORITY 2
+#define RP_PIPELINE_PREP_FAT_KERNELS 16 /* OR-ed in: keep the scheduling pass in its 256-thread form (A/B measurements; same order) */
 RP_API int rp_pipeline_set_prep(rp_pipeline *p, int mode);
 RP_API int rp_pipeline_submit(rp_pipeline *p, const double *d_pos0, const double *d_pos1, const double *d_pos2, rp_solution *d_out,
                               double gap_tol, int max_iter, void *inputs_stream, int64_t *job);

@@ -20,28 +20,30 @@ def burst(pipe, jobs):
 
 res = {}
 for rnd in range(3):
-    for name, kw in (("1 stream, inline", dict(depth=2, n_streams=1)), ("2 streams, inline", dict(depth=4, n_streams=2)),
-                     ("2 streams, prep stream", dict(depth=4, n_streams=2, prep=1)), ("2 streams, prep high priority", dict(depth=4, n_streams=2, prep=2)),
-                     ("1 stream, prep high priority", dict(depth=2, n_streams=1, prep=2)), ("3 streams, prep high priority", dict(depth=6, n_streams=3, prep=2)),
-                     ("2 streams depth 8, prep high priority", dict(depth=8, n_streams=2, prep=2))):
+    for name, kw in (("1 stream, inline", dict(depth=2, n_streams=1)), ("2 streams, inline (one-wave sched blocks)", dict(depth=4, n_streams=2)),
+                     ("2 streams, inline, 256-thread sched", dict(depth=4, n_streams=2, prep=16)),
+                     ("2 streams, prep stream", dict(depth=4, n_streams=2, prep=1)), ("2 streams, prep stream, 256-thread sched", dict(depth=4, n_streams=2, prep=17)),
+                     ("3 streams, inline", dict(depth=6, n_streams=3))):
         with rp.Pipeline(N, **kw) as pipe:
             burst(pipe, 160)                     # conditioning + first-use allocations
             t = time.perf_counter(); burst(pipe, JOBS); dt = (time.perf_counter() - t) / JOBS * 1e3
             tot = pipe.batch(JOBS + 160 - 1).reduce()["total_steps"]
         res.setdefault(name, []).append(dt)
         print("round %d  %-40s %.4f ms per job = %.2f G steps/s" % (rnd, name, dt, tot / dt / 1e6), flush=True)
-    # solve only, one stream and two (restart outside the clock is not possible in a burst: pre-armed batches)
+    # solve only, one stream and two: pre-armed batches (restart outside the clock)
     for ns in (1, 2):
-        bs = [rp.Batch(N) for _ in range(ns)]
-        pool = bs + [rp.Batch(N, stream=bs[j % ns].stream()) for j in range(JOBS + 160 - ns)]
-        for b in pool:
-            b.set_problems_device(*ptrs); b.restart()
-        for b in bs: b.sync()
-        for b in pool[:160]: b.solve(1e-8, 200, 0)
-        t = time.perf_counter()
-        for b in pool[160:]: b.solve(1e-8, 200, 0)
-        for b in bs: b.sync()
-        dt = (time.perf_counter() - t) / JOBS * 1e3
-        print("round %d  %-40s %.4f ms per solve = %.2f G steps/s" % (rnd, "solve only, %d stream(s)" % ns, dt, tot / dt / 1e6), flush=True)
+        heads = [rp.Batch(N) for _ in range(ns)]
+        pool = heads + [rp.Batch(N, stream=heads[j % ns].stream()) for j in range(40 - ns)]
+        for b in pool: b.set_problems_device(*ptrs)
+        best = None
+        for rep in range(3):
+            for b in pool: b.restart()
+            for b in heads: b.sync()
+            t = time.perf_counter()
+            for b in pool: b.solve(1e-8, 200, 0)
+            for b in heads: b.sync()
+            dt = (time.perf_counter() - t) / len(pool) * 1e3
+            best = dt if best is None else min(best, dt)
+        print("round %d  %-40s %.4f ms per solve = %.2f G steps/s" % (rnd, "solve only, %d stream(s)" % ns, best, tot / best / 1e6), flush=True)
         for b in pool[::-1]: b.close()
 print("best:", {k: round(min(v), 4) for k, v in res.items()})

@@ -87,8 +87,10 @@ hipError_t launch_clear_progress(const BatchView &b, hipStream_t stream);
 // order, zero the batch's progress counters and -- write_positions -- copy every problem's three positions into b.records;
 // d_scratch: schedule_scratch_bytes(n) bytes of device memory
 hipError_t schedule_scratch_bytes(size_t n, size_t *bytes);
+// one_wave_blocks: the form of the three kernels whose blocks are single waves (slower alone, able to run beside a solve: what
+// rp_pipeline uses); the order is the same either way
 hipError_t launch_schedule(const BatchView &b, const double *d_pos0, const double *d_pos1, const double *d_pos2, size_t pstride,
-                           bool write_positions, void *d_scratch, size_t scratch_bytes, hipStream_t stream);
+                           bool write_positions, void *d_scratch, size_t scratch_bytes, hipStream_t stream, bool one_wave_blocks = false);
 // d_dst[problem] = d_src[position of that problem] for per-problem words kept in batch order (requires b.scheduled)
 hipError_t launch_gather_u32(const BatchView &b, const uint32_t *d_src, uint32_t *d_dst, hipStream_t stream);
 

@@ -43,6 +43,7 @@ struct rp_batch {
                               // may write state the batch never sees, at any later time -- sticky until the next init / set_problems / set_state
                               // (which invalidate such pointers' meaning): while it is set, a bound solution buffer is seeded before EVERY gated
                               // launch that may skip problems, not only the first one after the hand-out
+    bool slim_schedule;       // the scheduling pass runs in its one-wave-per-block form (schedule.hip): set by rp_pipeline for its batches
     bool at_start;            // set_problems has run and nothing else since: the batch holds its scheduled order and its positions; the
                               // feasible start itself (mutable fields, progress words) is NOT materialised yet -- see materialize()
     double ungated_steps;     // per-problem count of ungated steps since the last init
@@ -121,7 +122,7 @@ int schedule(rp_batch *b, const double *d_pos0, const double *d_pos1, const doub
         RP_HIP(hipMalloc(&p, b->view.n * sizeof(rp::StartRecord)));
         b->view.records = (rp::StartRecord *)p;
     }
-    RP_HIP(rp::launch_schedule(b->view, d_pos0, d_pos1, d_pos2, pstride, write_positions, b->d_sched, b->sched_bytes, b->stream));
+    RP_HIP(rp::launch_schedule(b->view, d_pos0, d_pos1, d_pos2, pstride, write_positions, b->d_sched, b->sched_bytes, b->stream, b->slim_schedule));
     b->view.scheduled = true;
     return RP_OK;
 }
@@ -904,7 +905,8 @@ struct rp_pipeline {
     hipEvent_t *done;          // per slot: recorded behind the slot's last job
     hipEvent_t *consumed;      // per slot: recorded behind that job's scheduling pass (its position arrays have been read)
     hipEvent_t inputs_ready;   // scratch: recorded on the caller's stream in rp_pipeline_submit
-    hipStream_t prep;          // prep_mode != 0: the stream every job's scheduling pass runs on (its solve waits for it through `consumed`)
+    hipStream_t prep[4];       // prep_mode != 0: the streams the jobs' scheduling passes run on, job i on prep[i % n_prep] (its solve waits for it through `consumed`)
+    int n_prep;
     int prep_mode;             // RP_PIPELINE_PREP_*
     int64_t *job_of;           // per slot: the job it last took (-1: none)
     int64_t next_job;
@@ -934,10 +936,14 @@ int rp_pipeline_create(rp_pipeline **out, int variant, int dtype, size_t n, int 
         // the first batch of a stream creates it (a non-blocking stream of its own); the others of that stream share it
         st = rp_batch_create(&p->slots[j], variant, dtype, n, device, j < n_streams ? nullptr : (void *)p->streams[j % n_streams]);
         if (st == RP_OK && j < n_streams) p->streams[j] = p->slots[j]->stream;
+        if (st == RP_OK) p->slots[j]->slim_schedule = n_streams > 1;      // beside a running solve only one-wave blocks get in (schedule.hip)
         if (st == RP_OK && hipEventCreateWithFlags(&p->done[j], hipEventDisableTiming) != hipSuccess) st = fail(RP_ERR_DEVICE, "hipEventCreate failed");
         if (st == RP_OK && hipEventCreateWithFlags(&p->consumed[j], hipEventDisableTiming) != hipSuccess) st = fail(RP_ERR_DEVICE, "hipEventCreate failed");
     }
     if (st == RP_OK && hipEventCreateWithFlags(&p->inputs_ready, hipEventDisableTiming) != hipSuccess) st = fail(RP_ERR_DEVICE, "hipEventCreate failed");
+    // (default arrangement: the scheduling pass on the job's own stream.  A stream of its own for it -- rp_pipeline_set_prep -- measured the
+    // same to 1 % in a process that owns few streams and WORSE in one that owns many: the HIP runtime multiplexes streams onto a handful of
+    // hardware queues, GPU_MAX_HW_QUEUES = 4 by default, and two streams that share a queue serialise: profiles/r6_tuning.md)
     if (st != RP_OK) {
         char keep[sizeof g_err];
         std::memcpy(keep, g_err, sizeof keep);
@@ -962,7 +968,7 @@ int rp_pipeline_destroy(rp_pipeline *p)
         if (p->consumed && p->consumed[j]) (void)hipEventDestroy(p->consumed[j]);
     }
     if (p->inputs_ready) (void)hipEventDestroy(p->inputs_ready);
-    if (p->prep) { (void)hipStreamSynchronize(p->prep); (void)hipStreamDestroy(p->prep); }
+    for (int j = 0; j < p->n_prep; ++j) { (void)hipStreamSynchronize(p->prep[j]); (void)hipStreamDestroy(p->prep[j]); }
     delete[] p->slots;
     delete[] p->done;
     delete[] p->consumed;
@@ -974,16 +980,24 @@ int rp_pipeline_destroy(rp_pipeline *p)
 int rp_pipeline_set_prep(rp_pipeline *p, int mode)
 {
     if (!p) return fail(RP_ERR_INVALID, "null pipeline handle");
+    const bool fat = (mode & RP_PIPELINE_PREP_FAT_KERNELS) != 0;      // A/B: the 256-thread form of the pass whatever the arrangement
+    mode &= ~RP_PIPELINE_PREP_FAT_KERNELS;
     if (mode != RP_PIPELINE_PREP_INLINE && mode != RP_PIPELINE_PREP_STREAM && mode != RP_PIPELINE_PREP_PRIORITY)
         return fail(RP_ERR_INVALID, "prep mode %d (want 0 = on the job's stream, 1 = a stream of its own, 2 = ... with the highest priority)", mode);
     if (p->next_job != 0) return fail(RP_ERR_INVALID, "the arrangement is fixed once a job has been submitted");
     RP_HIP(hipSetDevice(p->device));
-    if (p->prep) { (void)hipStreamDestroy(p->prep); p->prep = nullptr; }
+    for (int j = 0; j < p->n_prep; ++j) (void)hipStreamDestroy(p->prep[j]);
+    p->n_prep = 0;
     p->prep_mode = mode;
+    for (int j = 0; j < p->depth; ++j) p->slots[j]->slim_schedule = !fat && (p->n_streams > 1 || mode != RP_PIPELINE_PREP_INLINE);
     if (mode == RP_PIPELINE_PREP_INLINE) return RP_OK;
     int least = 0, greatest = 0;
     if (mode == RP_PIPELINE_PREP_PRIORITY) RP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    RP_HIP(hipStreamCreateWithPriority(&p->prep, hipStreamNonBlocking, mode == RP_PIPELINE_PREP_PRIORITY ? greatest : 0));
+    // ONE prep stream: beside a running solve a pass takes about as long as the solve itself (three dependent, latency-bound kernels that
+    // share every SIMD with four solve waves), which one stream just sustains; a prep stream per solve stream was measured and is no
+    // faster -- two passes at once only contend (profiles/r6_pipeline_probe_two_prep_streams.log)
+    RP_HIP(hipStreamCreateWithPriority(&p->prep[0], hipStreamNonBlocking, mode == RP_PIPELINE_PREP_PRIORITY ? greatest : 0));
+    p->n_prep = 1;
     return RP_OK;
 }
 
@@ -1007,16 +1021,17 @@ int rp_pipeline_submit(rp_pipeline *p, const double *d_pos0, const double *d_pos
     rp_batch *b = p->slots[slot];
     // The scheduling pass runs on the job's own stream or -- prep_mode -- on the pipeline's prep stream, behind the slot's previous job
     // (it overwrites the batch's order and records) and ahead of this job's solve (which waits for `consumed`).
-    hipStream_t solve_stream = b->stream, sched_stream = p->prep ? p->prep : b->stream;
+    hipStream_t prep = p->n_prep ? p->prep[id % p->n_prep] : nullptr;
+    hipStream_t solve_stream = b->stream, sched_stream = prep ? prep : b->stream;
     if (inputs_stream && (hipStream_t)inputs_stream != sched_stream) {      // the positions are produced by work on the caller's stream: wait for it, on the device
         RP_HIP(hipEventRecord(p->inputs_ready, (hipStream_t)inputs_stream));
         RP_HIP(hipStreamWaitEvent(sched_stream, p->inputs_ready, 0));
     }
     int st = rp_batch_bind_solution(b, d_out);
     if (st != RP_OK) return st;
-    if (p->prep) {
-        if (p->job_of[slot] >= 0) RP_HIP(hipStreamWaitEvent(p->prep, p->done[slot], 0));
-        b->stream = p->prep;
+    if (prep) {
+        if (p->job_of[slot] >= 0) RP_HIP(hipStreamWaitEvent(prep, p->done[slot], 0));
+        b->stream = prep;
         st = rp_batch_set_problems_device(b, d_pos0, d_pos1, d_pos2);
         b->stream = solve_stream;
     } else {
@@ -1024,7 +1039,7 @@ int rp_pipeline_submit(rp_pipeline *p, const double *d_pos0, const double *d_pos
     }
     if (st != RP_OK) return st;
     RP_HIP(hipEventRecord(p->consumed[slot], sched_stream));
-    if (p->prep) RP_HIP(hipStreamWaitEvent(solve_stream, p->consumed[slot], 0));
+    if (prep) RP_HIP(hipStreamWaitEvent(solve_stream, p->consumed[slot], 0));
     st = rp_batch_solve(b, gap_tol, max_iter, 0);
     if (st != RP_OK) return st;
     RP_HIP(hipEventRecord(p->done[slot], b->stream));
@@ -1048,7 +1063,7 @@ int rp_pipeline_wait(rp_pipeline *p, int64_t job)
     if (!p) return fail(RP_ERR_INVALID, "null pipeline handle");
     RP_HIP(hipSetDevice(p->device));
     if (job < 0) {      // everything submitted so far
-        if (p->prep) RP_HIP(hipStreamSynchronize(p->prep));      // (first: a solve stream's last solve waits on it)
+        for (int j = 0; j < p->n_prep; ++j) RP_HIP(hipStreamSynchronize(p->prep[j]));      // (first: a solve stream's last solve waits on them)
         for (int j = 0; j < p->n_streams; ++j) RP_HIP(hipStreamSynchronize(p->streams[j]));
         return RP_OK;
     }

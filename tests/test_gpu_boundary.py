@@ -683,6 +683,11 @@ def test_pipeline_results_are_the_one_stream_paths_bit_for_bit(oracle):
                 assert r["n_converged"] == n and r["total_steps"] == float(expect[-1]["iters"].sum())
                 st = last.get_state()
                 assert np.array_equal(st[:, 0], expect[-1]["vel1"]) and np.array_equal(st[:, 2], expect[-1]["duration1"])
+                # with more than one stream the pipeline's batches run the scheduling pass in its one-wave-per-block form (schedule.hip,
+                # slim::): the order it leaves must be the very order of the 256-thread form -- the stable sort by key is unique
+                with rp.Batch(n) as plain:
+                    plain.set_problems(*probs[-1])
+                    assert np.array_equal(last.slot_map(), plain.slot_map()), n_streams
                 with pytest.raises(rp.RpError):
                     pipe.batch(ids[0])
                 with pytest.raises(rp.RpError):
