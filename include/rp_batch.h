@@ -47,8 +47,8 @@ typedef struct rp_batch rp_batch; /* opaque, owned by the caller between create 
  *   4  round 4: rp_solution records (rp_batch_solution_device, rp_batch_bind_solution); rp_batch_traffic_probe replaces an
  *      environment switch; the library reads nothing from the environment; rp_batch_sample_device checks its alignment
  *   5  round 5: rp_device_id; a bound solution buffer is seeded before a gated launch that skips finished problems
- *   6  round 6: rp_pipeline_* (positions in -> solutions out over several streams); a raw pointer to a mutable field keeps the
- *      seeding pass on for every later gated launch */
+ *   6  round 6: rp_pipeline_* (positions in -> solutions out over several streams); rp_params + handoff_rounds / handoff_lanes (the gated
+ *      solve in rounds); a raw pointer to a mutable field keeps the seeding pass on for every later gated launch */
 #define RP_ABI_VERSION 6
 
 typedef enum {
@@ -100,6 +100,21 @@ typedef struct {
                                  else the reference step.  Same optimum in fewer steps (15.4 -> 12.7 mean on the benchmark distribution);
                                  double arithmetic only */
     double mu_sigma_try[2];   /* 0.01, 0.03 */
+    int32_t handoff_rounds;   /* How the fused gated solve (rp_batch_solve with steps_per_launch <= 0) treats states its internal order says
+                                 nothing about -- states that were set, nudged, moved or handed out raw since the last set_problems / init
+                                 (reference mode only: mu_mode 0, no stall detector).
+                                 0 (default): such a batch runs the kernel that WATCHES FOR FIXED POINTS: a problem whose step leaves
+                                 its state bit for bit unchanged -- a start outside the feasible set: 100 feasibility halvings, no
+                                 movement, onedpath_ip.cpp:919-928 -- takes its remaining step budget as read; count, status and state are
+                                 exactly what stepping on would leave, without the ~20,000 evaluations.  Everything else (and the
+                                 benchmark's path: set_problems -> solve) runs the plain kernel.
+                                 2..8: additionally IN ROUNDS: a wave runs until its slowest lane is done, so one problem that needs 60
+                                 steps holds 63 finished neighbours; in rounds a wave whose stepping lanes have numbered <= handoff_lanes
+                                 for more than one step stops and leaves them open, the next launch packs all open problems densely,
+                                 the last round runs to the end.  Same steps per problem, same results.  Pays only where most lane-steps
+                                 would idle (measured: profiles/r6_state_families.log); costs 10-30 % where they would not.
+                                 -1: the plain kernel always. */
+    int32_t handoff_lanes;    /* 24 (1..48) */
 } rp_params;
 
 /* Batch-wide reduction, the payload of the one cross-GPU collective (max / max / sum / sum). */

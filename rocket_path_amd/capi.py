@@ -28,7 +28,8 @@ class Params(ctypes.Structure):
     _fields_ = [("accel_limit", ctypes.c_double), ("mu_divisor", ctypes.c_double),
                 ("boundary_fraction", ctypes.c_double), ("backtrack", ctypes.c_double),
                 ("armijo", ctypes.c_double), ("max_backtracks", ctypes.c_int32), ("stall_window", ctypes.c_int32),
-                ("mu_mode", ctypes.c_int32), ("mu_sigma_try", ctypes.c_double * 2)]
+                ("mu_mode", ctypes.c_int32), ("mu_sigma_try", ctypes.c_double * 2),
+                ("handoff_rounds", ctypes.c_int32), ("handoff_lanes", ctypes.c_int32)]
 
 
 class Solution(ctypes.Structure):

@@ -160,6 +160,8 @@ template <typename T> struct KParams {
     int max_bt;     // 100
     int stall_window;   // 0 = off; see rp_params.stall_window
     T sigma_try[2];     // mu_mode 1: centring parameters tried (ascending) before the reference's 1/mu_divisor; see newton_step
+    int handoff_lanes, handoff_patience;      // the gated solve's straggler hand-off (k_solve_chunks<ROUNDS>): a wave whose stepping lanes have numbered <=
+                                              // handoff_lanes for more than handoff_patience steps stops and leaves them open (0 lanes: never)
 };
 
 // The per-problem constants the step needs (enum V 11..15 reduced to velocities and deltas).

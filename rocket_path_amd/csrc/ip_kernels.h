@@ -42,6 +42,7 @@ struct BatchView {
     Solution *solution;    // bound by rp_batch_bind_solution (null: none): gated solves write each problem's record there, problem order
     int iters_add;         // ungated steps taken since the last init, added to the iteration counts that leave the batch in records
     unsigned long long *counters;   // 128 words: [0,64) shards of "problems still open after the last gated launch", [64,128) shards of gated steps executed
+    uint32_t *lists;       // 2 n + 16 words (null until needed): two position lists + the rounds' counts -- the straggler hand-off of the gated solve
 };
 
 struct HostParams {
@@ -50,6 +51,8 @@ struct HostParams {
     int stall_window;
     int mu_mode;                 // 0 = reference centring, 1 = centring by trial (ip_core.h, newton_step)
     double mu_sigma_try[2];      // the two candidates of mode 1
+    int handoff_rounds;          // rp_params.handoff_rounds: 0 = automatic, -1 = never, 2..8 = always that many rounds
+    int handoff_lanes;           // rp_params.handoff_lanes
 };
 
 inline int state_len(int variant) { return variant == 4 ? 12 : 16; }
@@ -66,6 +69,12 @@ hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double 
 // scheduled, schedule.hip) and every problem begins at its feasible start, formed in registers (reference mode, no stall
 // detector, zero end velocities only)
 hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, bool from_start, hipStream_t stream);
+// the same for states the batch's order says nothing about (k_solve_chunks<ROUNDS>): a problem whose step leaves its state bit for bit
+// unchanged -- a start outside the feasible set -- takes its remaining budget as read (exact), and with rounds > 1 (b.lists must exist) the
+// solve runs in ROUNDS: the first launch walks the whole batch and every wave hands its last `lanes` stragglers off -- leaves them open
+// and appends their positions to a list -- once they have stepped alone for more than `patience` steps; each further launch walks the
+// previous one's list, densely packed, the last one to the end.  Same per-problem arithmetic: same results.
+hipError_t launch_solve_rounds(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, int rounds, int lanes, int patience, hipStream_t stream);
 // max ||r||^2, max gap, #converged, gated steps (+ host_steps) -> d_out4 (device); d_partials has 4 * 1024 doubles.
 hipError_t launch_reduce(const BatchView &b, const HostParams &hp, double host_steps, double *d_partials,
                          double *d_out4, hipStream_t stream);

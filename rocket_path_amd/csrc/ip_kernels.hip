@@ -76,6 +76,8 @@ template <typename T> KParams<T> make_kparams(const HostParams &hp, int variant)
     kp.stall_window = hp.stall_window;
     kp.sigma_try[0] = (T)hp.mu_sigma_try[0];
     kp.sigma_try[1] = (T)hp.mu_sigma_try[1];
+    kp.handoff_lanes = 0;
+    kp.handoff_patience = 0;
     return kp;
 }
 
@@ -153,7 +155,7 @@ constexpr bool kStepInPlace = RP_GATED_IN_PLACE && MU == 0 && (GATED ? std::is_s
 #define RP_PARK_FIXED_POINTS 1      // 0: every lane takes every step (A/B builds: no bit may change)
 #endif
 template <typename T, int VARIANT, bool GATED, bool STALL = GATED, class P = Prob<T>, typename S = T, bool AFFINE = false, int MU = 0, class D = NoDiag, int WAVE = 0,
-          class BK = LdsColumn<T>, bool PARK = false>
+          class BK = LdsColumn<T>, bool PARK = false, bool ROUNDS = false>
 __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int k, T tol, int max_iter,
                                          T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                          int &it, uint32_t &st, int &steps_here, bool &still_open, D &diag, BK backup = BK{})
@@ -201,10 +203,19 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
         // is live after it -- the whole state -- at every trip.)  The test is a ballot over the gate's own comparisons -- a lane
         // that has passed its gate passes it again, its state no longer moves -- and the status bits are read off the final
         // point afterwards: nothing is carried round the loop but the state.
+        [[maybe_unused]] int lonely = 0;      // ROUNDS: steps this wave has taken with no more than kp.handoff_lanes of its lanes stepping
         for (int s = 0; s < k; ++s) {
             const T gap = current_gap();
             const bool above = !(gap < tol), may = left > 0;
-            if ((__builtin_amdgcn_ballot_w64(above) & __builtin_amdgcn_ballot_w64(may)) == 0ull) break;      // (two ballots, each its comparison's own lane mask)
+            const unsigned long long stepping = __builtin_amdgcn_ballot_w64(above) & __builtin_amdgcn_ballot_w64(may);      // (two ballots, each its comparison's own lane mask)
+            if (stepping == 0ull) break;
+            if constexpr (ROUNDS) {
+                // Straggler hand-off: a wave runs until its slowest lane is done, and with step counts that nothing predicted (states that
+                // did not come from the feasible-start rule: nudged, set, restored) one lane that needs 200 steps holds 63 finished ones for
+                // 185.  When only a few lanes are still stepping, and have been for `patience` steps, the wave stops; those lanes stay open,
+                // their positions go onto a list (k_solve_chunks) and the next launch of the solve packs them densely into new waves.
+                if (__popcll(stepping) <= kp.handoff_lanes) { if (++lonely > kp.handoff_patience) break; }
+            }
             if (above && may) {
                 if constexpr (INPLACE)
                     newton_step_inplace<T, VARIANT, P, BK>(pr, kp, gap, v, t0, t1, lam, e, backup, halvings);      // the step's start waits in LDS, the accepted trial is the state
@@ -217,6 +228,25 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                     evaluate();                      // the carried evaluation belongs to the unrounded point
                 }
                 --left;
+                if constexpr (ROUNDS && INPLACE) {
+                    // Fixed points use their budget up at once (exact).  A start outside the feasible set -- a nudged velocity, durations
+                    // cut short: what SURVEY 8f's callers feed in -- makes no progress in the reference: 100 feasibility halvings
+                    // (onedpath_ip.cpp:919-928), x + s dx is x bit for bit, and so are the multipliers; the next step starts from the same
+                    // bits and does the same again, up to the step budget: 200 steps of a hundred evaluations each for one lane, holding its
+                    // wave.  The step is a function of the state (the carried evaluation is a function of it too: formed by the same
+                    // expressions at the same point), so a state it maps onto itself stays: the lane takes its remaining steps as read --
+                    // the count, the status and every bit it stores are what stepping on would have left.  The step's start is still in the
+                    // LDS column: one read and one compare per step screen (vel1 unchanged, which a moving iterate never shows), the other
+                    // ten behind a branch that is taken when some lane passes the screen.
+                    const bool v_same = __builtin_bit_cast(unsigned long long, (double)v) == __builtin_bit_cast(unsigned long long, (double)(T)backup.get(0));
+                    if (__builtin_amdgcn_ballot_w64(v_same) != 0ull) {
+                        bool same = v_same && t0 == (T)backup.get(1) && t1 == (T)backup.get(2);      // (durations are positive and finite: value equality is bit equality)
+#pragma unroll
+                        for (int c = 0; c < CMap<VARIANT>::NC; ++c)
+                            same = same && __builtin_bit_cast(unsigned long long, (double)lam[c]) == __builtin_bit_cast(unsigned long long, (double)(T)backup.get(3 + c));
+                        if (same) left = 0;
+                    }
+                }
             }
         }
     } else if constexpr (GATED) {
@@ -399,18 +429,33 @@ __device__ unsigned long long g_trace[4 * 32768];
 // unconditionally.  That spares a fresh batch the 128 B per problem the feasible start would write, the 88 B of them this
 // kernel would read back, and the progress words' clearing pass.
 // (mu_mode 1 carries the split direction: ~210 VGPRs, two waves per SIMD)
-template <typename S, typename T, int VARIANT, bool STALL, bool ZV, int MU = 0, bool START = false>
+// ROUNDS (rp_params.handoff_rounds; never the benchmark's fresh batches): the launch is one round of a solve in rounds.  `list_in` (null: the
+// whole batch) holds the POSITIONS this round walks, `list_count` their number; a wave that stops with lanes still open (run_lane's hand-off)
+// appends their positions to `list_out` (null in the last round, which runs every lane to its end).  Gathered 8-byte accesses instead of
+// coalesced ones from the second round on -- for the few per cent of a batch that get that far.
+template <typename S, typename T, int VARIANT, bool STALL, bool ZV, int MU = 0, bool START = false, bool ROUNDS = false>
 __global__ void __launch_bounds__(64, MU == 1 ? RP_NEWTON_WAVES : (STALL && RP_GATED_WAVES > 3) ? 3 : RP_GATED_WAVES)
 k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> kp, T tol, int max_iter,
                int32_t *__restrict__ iters, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
                const StartRecord *__restrict__ records, const uint32_t *__restrict__ prob_of, double start_limit,
-               Solution *__restrict__ solution, const uint32_t *__restrict__ sol_prob_of, int iters_add)
+               Solution *__restrict__ solution, const uint32_t *__restrict__ sol_prob_of, int iters_add,
+               const uint32_t *__restrict__ list_in = nullptr, const uint32_t *__restrict__ list_count = nullptr,
+               uint32_t *__restrict__ list_out = nullptr, uint32_t *__restrict__ list_out_count = nullptr)
 {
     constexpr int NC = CMap<VARIANT>::NC;
     constexpr int CB = 3 + NC;   // first constant field: pos0, vel0, pos1, pos2, vel2
+    static_assert(!(ROUNDS && (START || STALL || MU != 0)), "rounds exist for the plain gated solve of a materialised batch");
     RP_TRACE_BEGIN();
     const unsigned chunk = gridDim.x - 1 - blockIdx.x;      // the scheduled order ends with the longest problems: they start first
-    const size_t i = (size_t)chunk * 64 + threadIdx.x;
+    size_t i = (size_t)chunk * 64 + threadIdx.x;
+    if constexpr (ROUNDS) {
+        if (list_in) {      // this round's problems: entry i of the previous round's list (the grid is sized for the most that list can hold)
+            const size_t count = (size_t)*list_count;
+            if ((size_t)chunk * 64 >= count) return;
+            const size_t e = i;
+            i = e < count ? (size_t)list_in[e] : n;      // (n: no problem)
+        }
+    }
 
     int it = 0;
     uint32_t st = 0;
@@ -474,8 +519,9 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
             pl.dx0.at = col + (3 + NC) * 64;
             pl.dx1.at = col + (3 + NC + 1) * 64;
             NoDiag none;
-            run_lane<T, VARIANT, true, STALL, ProbLds<T, ZV>, S, false, MU, NoDiag, false>(pl, kp, k, tol, max_iter, v, t0, t1, lam, it_new, flags, steps_here, still_open, none, LdsColumn<T>{col});
+            run_lane<T, VARIANT, true, STALL, ProbLds<T, ZV>, S, false, MU, NoDiag, 0, LdsColumn<T>, false, ROUNDS>(pl, kp, k, tol, max_iter, v, t0, t1, lam, it_new, flags, steps_here, still_open, none, LdsColumn<T>{col});
         } else {
+            static_assert(!ROUNDS, "rounds are built on the in-place step's launch shape");
             run_lane<T, VARIANT, true, STALL, Prob<T, ZV>, S, false, MU>(pr, kp, k, tol, max_iter, v, t0, t1, lam, it_new, flags, steps_here, still_open);
         }
         // the store addresses are formed only now (the barrier keeps the compiler from holding them in registers across the steps),
@@ -484,6 +530,7 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
         asm volatile("" : "+v"(zero));      // (opaque, or the count is merged with one taken before the steps and held in a register through them)
         size_t j = (size_t)chunk * 64 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
         asm volatile("" : "+v"(j));
+        if constexpr (ROUNDS) { if (list_in) j = (size_t)list_in[j]; }      // (read again rather than held through the steps; an active lane's entry exists)
         if constexpr (START) {
             steps_here = it_new;
             it = it_new;
@@ -519,6 +566,19 @@ k_solve_chunks(S *__restrict__ base, size_t stride, size_t n, int k, KParams<T> 
 
     RP_TRACE_END(blockIdx.x, steps_here);
     const unsigned long long open_mask = __ballot(still_open);
+    if constexpr (ROUNDS) {
+        if (list_out && open_mask) {      // this wave's open lanes onto the next round's list: one atomic per wave, positions packed in lane order
+            const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            uint32_t at = 0;
+            if (lane == (unsigned)(__ffsll((long long)open_mask) - 1)) at = atomicAdd(list_out_count, (uint32_t)__popcll(open_mask));
+            at = __shfl(at, __ffsll((long long)open_mask) - 1);
+            if (still_open) {
+                size_t mine = (size_t)chunk * 64 + lane;
+                if (list_in) mine = (size_t)list_in[mine];
+                list_out[at + (uint32_t)__popcll(open_mask & ((1ull << lane) - 1ull))] = (uint32_t)mine;
+            }
+        }
+    }
     const int steps_wave = wave_sum<int>(steps_here);
     if (threadIdx.x == 0) {
         const unsigned shard = blockIdx.x & (kShards - 1);
@@ -1454,6 +1514,35 @@ hipError_t launch_solve_fused(const BatchView &b, const HostParams &hp, double g
     if (b.n == 0) return hipSuccess;
     // (the open-lane shards are not zeroed here: only the host-polled loop reads them, and launch_solve zeroes them itself)
     return launch_chunks(b, hp, max_iter > 0 ? max_iter : 1, gap_tol, max_iter, from_start, stream);
+}
+
+hipError_t launch_solve_rounds(const BatchView &b, const HostParams &hp, double gap_tol, int max_iter, int rounds, int lanes, int patience, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    if ((rounds > 1 && !b.lists) || hp.mu_mode != 0 || hp.stall_window > 0 || rounds < 1 || rounds > 8 || lanes < 1 || lanes > 48 || max_iter <= 0) return hipErrorInvalidValue;
+    uint32_t *list[2] = {b.lists, b.lists ? b.lists + b.n : nullptr}, *counts = b.lists ? b.lists + 2 * b.n : nullptr;      // counts[r]: entries of the list round r wrote
+    hipError_t e = rounds > 1 ? hipMemsetAsync(counts, 0, 16 * sizeof(uint32_t), stream) : hipSuccess;
+    if (e != hipSuccess) return e;
+    size_t bound = b.n;      // the most problems this round can be given
+    for (int r = 0; r < rounds; ++r) {
+        const bool last = r == rounds - 1;
+        const unsigned waves = (unsigned)((bound + 63) / 64);
+        const uint32_t *in = r == 0 ? nullptr : list[(r - 1) & 1], *in_count = r == 0 ? nullptr : counts + (r - 1);
+        uint32_t *out = last ? nullptr : list[r & 1], *out_count = last ? nullptr : counts + r;
+        RP_DISPATCH_Z(b, {
+            KParams<T> kp = make_kparams<T>(hp, V);
+            kp.handoff_lanes = last ? 0 : lanes;
+            kp.handoff_patience = patience;
+            hipLaunchKernelGGL((k_solve_chunks<S, T, V, false, Z, 0, false, true>), dim3(waves), dim3(64), 0, stream, (S *)b.base, b.stride, b.n, max_iter,
+                               kp, (T)gap_tol, max_iter, b.iters, b.status, b.counters, b.records, b.prob_of, hp.accel_limit, b.solution,
+                               b.scheduled ? (const uint32_t *)b.prob_of : nullptr, b.iters_add, in, in_count, out, out_count);
+        });
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        bound = (size_t)waves * (size_t)lanes;      // every wave hands off at most `lanes` of its lanes
+        if (bound > b.n) bound = b.n;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_solve(const BatchView &b, const HostParams &hp, int k, double gap_tol, int max_iter, hipStream_t stream)

@@ -43,6 +43,8 @@ struct rp_batch {
                               // may write state the batch never sees, at any later time -- sticky until the next init / set_problems / set_state
                               // (which invalidate such pointers' meaning): while it is set, a bound solution buffer is seeded before EVERY gated
                               // launch that may skip problems, not only the first one after the hand-out
+    bool unpredicted;         // the state has been set, nudged, moved or handed out raw since the last set_problems / init: the batch's internal order
+                              // no longer predicts step counts, and the fused gated solve runs in rounds (rp_params.handoff_rounds = 0: automatic)
     bool slim_schedule;       // the scheduling pass runs in its one-wave-per-block form (schedule.hip): set by rp_pipeline for its batches
     bool at_start;            // set_problems has run and nothing else since: the batch holds its scheduled order and its positions; the
                               // feasible start itself (mutable fields, progress words) is NOT materialised yet -- see materialize()
@@ -96,6 +98,8 @@ void default_params(rp::HostParams &hp)
     hp.mu_mode = 0;
     hp.mu_sigma_try[0] = 0.01;
     hp.mu_sigma_try[1] = 0.03;
+    hp.handoff_rounds = 0;
+    hp.handoff_lanes = 24;
 }
 
 int reset_progress(rp_batch *b)
@@ -249,6 +253,8 @@ void rp_params_default(rp_params *p)
     p->mu_mode = hp.mu_mode;
     p->mu_sigma_try[0] = hp.mu_sigma_try[0];
     p->mu_sigma_try[1] = hp.mu_sigma_try[1];
+    p->handoff_rounds = hp.handoff_rounds;
+    p->handoff_lanes = hp.handoff_lanes;
 }
 
 int rp_batch_create(rp_batch **out, int variant, int dtype, size_t n, int device, void *stream)
@@ -321,6 +327,7 @@ int rp_batch_destroy(rp_batch *b)
     if (b->view.slot_of) (void)hipFree(b->view.slot_of);
     if (b->view.prob_of) (void)hipFree(b->view.prob_of);
     if (b->view.records) (void)hipFree(b->view.records);
+    if (b->view.lists) (void)hipFree(b->view.lists);
     if (b->d_words) (void)hipFree(b->d_words);
     if (b->d_sched) (void)hipFree(b->d_sched);
     if (b->view.counters) (void)hipFree(b->view.counters);
@@ -343,6 +350,9 @@ int rp_batch_set_params(rp_batch *b, const rp_params *p)
         p->max_backtracks > 4096 || p->stall_window < 0)      // every device loop must stay short: a runaway kernel takes the GPU with it
         return fail(RP_ERR_INVALID, "parameter out of range");
     if (p->mu_mode != 0 && p->mu_mode != 1) return fail(RP_ERR_INVALID, "mu_mode %d (want 0 = reference or 1 = centring by trial)", p->mu_mode);
+    if (!(p->handoff_rounds == 0 || p->handoff_rounds == -1 || (p->handoff_rounds >= 2 && p->handoff_rounds <= 8)))
+        return fail(RP_ERR_INVALID, "handoff_rounds %d (want 0 = automatic, -1 = never, or 2..8)", p->handoff_rounds);
+    if (p->handoff_lanes < 1 || p->handoff_lanes > 48) return fail(RP_ERR_INVALID, "handoff_lanes %d (want 1..48)", p->handoff_lanes);
     if (p->mu_mode == 1) {
         if (b->view.dtype == RP_DTYPE_F32) return fail(RP_ERR_UNSUPPORTED, "mu_mode 1 needs double arithmetic (RP_DTYPE_F64 or RP_DTYPE_F32_STATE)");
         if (!(p->mu_sigma_try[0] > 0 && p->mu_sigma_try[0] <= p->mu_sigma_try[1] && p->mu_sigma_try[1] < 1))
@@ -366,6 +376,8 @@ int rp_batch_set_params(rp_batch *b, const rp_params *p)
     b->params.mu_mode = p->mu_mode;
     b->params.mu_sigma_try[0] = p->mu_sigma_try[0];
     b->params.mu_sigma_try[1] = p->mu_sigma_try[1];
+    b->params.handoff_rounds = p->handoff_rounds;
+    b->params.handoff_lanes = p->handoff_lanes;
     return RP_OK;
 }
 
@@ -382,6 +394,8 @@ int rp_batch_get_params(const rp_batch *b, rp_params *p)
     p->mu_mode = b->params.mu_mode;
     p->mu_sigma_try[0] = b->params.mu_sigma_try[0];
     p->mu_sigma_try[1] = b->params.mu_sigma_try[1];
+    p->handoff_rounds = b->params.handoff_rounds;
+    p->handoff_lanes = b->params.handoff_lanes;
     return RP_OK;
 }
 
@@ -414,6 +428,7 @@ int rp_batch_init_default(rp_batch *b)
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
     b->sol_stale = true;
     b->raw_state_out = false;
+    b->unpredicted = false;      // identical problems: identical step counts
     b->view.zero_end_vel = true;
     b->view.scheduled = false;         // identical problems: nothing to schedule
     b->at_start = false;
@@ -432,6 +447,7 @@ int rp_batch_init_stuck(rp_batch *b)
     RP_HIP(rp::launch_init_const(b->view, s, b->stream));
     b->sol_stale = true;
     b->raw_state_out = false;
+    b->unpredicted = false;      // identical problems: identical step counts
     b->view.zero_end_vel = true;
     b->view.scheduled = false;
     b->at_start = false;
@@ -457,6 +473,7 @@ int rp_batch_set_problems_device(rp_batch *b, const double *d_pos0, const double
     b->ungated_steps = 0.0;
     b->sol_stale = true;
     b->raw_state_out = false;
+    b->unpredicted = false;      // the feasible-start rule: what the scheduled order was fitted to
     b->at_start = true;
     b->records_current = true;
     return RP_OK;
@@ -466,6 +483,7 @@ int rp_batch_restart(rp_batch *b)
 {
     RP_NEED(b);
     b->sol_stale = true;
+    if (!b->raw_positions_out) b->unpredicted = false;      // back on the feasible start of the positions the order was computed from
     if (b->at_start) return materialize(b);      // already at the start of its positions: write it out
     RP_HIP(rp::launch_restart_feasible(b->view, b->params, b->stream));
     b->view.zero_end_vel = true;
@@ -511,6 +529,7 @@ int rp_batch_set_state(rp_batch *b, const double *aos)
         b->records_current = false;
         b->sol_stale = true;
         b->raw_state_out = false;
+        b->unpredicted = true;      // any state: the order (computed from the positions in the rows) predicts nothing about it
     }
     RP_HIP(rp::launch_aos_to_soa(b->view, b->d_aos, b->stream));
     st = reset_progress(b);
@@ -554,6 +573,7 @@ int rp_batch_nudge(rp_batch *b, int var_index, double delta)
     if (var_index < 0 || var_index >= rp::state_len(b->view.variant)) return fail(RP_ERR_INVALID, "variable index %d out of range", var_index);
     RP_HIP(rp::launch_nudge(b->view, var_index, delta, b->stream));
     b->sol_stale = true;
+    b->unpredicted = true;
     if (var_index >= 3 + rp::num_constraints(b->view.variant)) b->records_current = false;      // a constant moved: the records no longer are the batch's positions
     {
         const int iv0 = 3 + rp::num_constraints(b->view.variant) + 1, iv2 = iv0 + 3;
@@ -619,7 +639,19 @@ int rp_batch_solve(rp_batch *b, double gap_tol, int max_iter, int steps_per_laun
         else { const int ms = materialize(b); if (ms != RP_OK) return ms; }
         b->view.iters_add = (int)b->ungated_steps;
         if (!from_start) { const int ss = seed_solution(b); if (ss != RP_OK) return ss; }      // (the START launch stores every record itself)
-        RP_HIP(rp::launch_solve_fused(b->view, b->params, gap_tol, max_iter, from_start, b->stream));
+        // in rounds (rp_params.handoff_rounds): states the batch's order says nothing about -- reference mode only, and a batch big enough for a second wave
+        // A batch whose state has been set, nudged, moved or handed out raw runs the kernel that watches for fixed points (starts outside the
+        // feasible set use their budget up at once instead of walking a hundred halvings two hundred times: exact); rounds on request
+        const bool plain = from_start || b->params.mu_mode != 0 || b->params.stall_window > 0 || max_iter <= 0;
+        int rounds = b->params.handoff_rounds >= 2 ? b->params.handoff_rounds : 1;
+        if (b->view.n <= 64) rounds = 1;
+        const bool watched = !plain && b->params.handoff_rounds != -1 && (b->unpredicted || rounds > 1);
+        if (watched) {
+            if (rounds > 1 && !b->view.lists) RP_HIP(hipMalloc((void **)&b->view.lists, (2 * b->view.n + 16) * sizeof(uint32_t)));
+            RP_HIP(rp::launch_solve_rounds(b->view, b->params, gap_tol, max_iter, rounds, b->params.handoff_lanes, 1, b->stream));
+        } else {
+            RP_HIP(rp::launch_solve_fused(b->view, b->params, gap_tol, max_iter, from_start, b->stream));
+        }
         b->sol_stale = false;      // only now: a launch that failed has written no record
         return RP_OK;
     }
@@ -658,6 +690,7 @@ int rp_batch_move_toward_feasibility(rp_batch *b)
     RP_NEED_STATE(b);
     RP_HIP(rp::launch_move_toward_feasibility(b->view, b->params, b->stream));
     b->sol_stale = true;
+    b->unpredicted = true;
     return RP_OK;
 }
 
@@ -868,6 +901,7 @@ int rp_batch_field_ptr(rp_batch *b, int field, void **d_ptr)
     b->sol_stale = true;
     if (field >= 3 + rp::num_constraints(b->view.variant)) b->raw_positions_out = true;      // ... now or at any later time: sticky (see the struct)
     else b->raw_state_out = true;                                                            // ... and so may the state: every later gated launch seeds a bound buffer first
+    b->unpredicted = true;
     {   // a caller holding a raw pointer to an end-velocity field may write non-zero values the batch never sees: from
         // here on (until the next init / set_problems / set_state) the Newton kernels read vel0X and vel2X
         const int iv0 = 3 + rp::num_constraints(b->view.variant) + 1, iv2 = iv0 + 3;

@@ -1010,6 +1010,133 @@ def test_f4_wave_parallel_line_search_equals_single_steps_bitwise(dtype):
         assert (nr > 20).sum() > 30, (nr > 20).sum()      # ... so the service did run on the other side (fp64: ~1 % of the problems, fp32: a few dozen)
 
 
+def _unpredicted_states(oracle, n, seed, family):
+    """States whose step counts the batch's internal order says nothing about (what nudges, set_state and
+    restored starts feed in): a few problems in each need several times the typical count, some the whole budget."""
+    rng = np.random.default_rng(seed)
+    p0, p1, p2 = rp.problems.generate(seed, 0, n, rp.problems.DIST_NON_MONOTONE if family == "durations" else rp.problems.DIST_MONOTONE)
+    st = oracle.batch_init_feasible(3, p0, p1, p2)
+    if family == "multipliers":
+        st[:, 3:11] = 10.0 ** rng.uniform(-3, 2, (n, 1))
+    elif family == "vel1":
+        st[:, 0] = rng.uniform(-10, 10, n)
+    elif family == "durations":
+        st[:, 1] += rng.choice([0.0, 0.1, 1.0], n)
+        st[:, 2] += rng.choice([0.0, 0.1, 1.0], n)
+    return st
+
+
+@pytest.mark.parametrize("family", ["multipliers", "vel1", "durations"])
+def test_gated_solve_in_rounds_gives_every_problem_the_steps_of_the_single_launch(oracle, family):
+    # VERDICT r5 next 4: states entered through set_state (multipliers != 1, a nudged velocity, nudged durations) have step counts the
+    # scheduled order does not predict -- a few problems need 60 or 200 steps and hold their wave's other 63 lanes.  The fused solve then
+    # runs in rounds (rp_params.handoff_rounds, automatic after set_state): waves hand their last stragglers off, later launches pack
+    # them densely.  Which lane runs a problem changes nothing: states, multipliers, iteration counts, status words and the bound
+    # solution records must be bit for bit those of ONE launch (handoff_rounds = -1), for every round count, a small lane threshold,
+    # a step budget that ends mid-solve, and a resumed solve.  The oracle checks the answers themselves.
+    from hip_util import DeviceBuffer
+    n = 48 * 1024 + 21
+    st0 = _unpredicted_states(oracle, n, 4711, family)
+    dt = np.dtype(rp.capi.SOLUTION_FIELDS)
+    ref = {}
+    with rp.Batch(n) as one, DeviceBuffer(32 * n) as out:
+        one.set_params(handoff_rounds=-1)
+        one.bind_solution(out.ptr)
+        for cap in (200, 9):
+            one.set_state(st0)
+            one.solve(1e-8, cap, 0)
+            ref[cap] = (one.get_state(), one.get_iters(), out.read(dt).copy(), one.reduce())
+        one.solve(1e-8, 200, 0)                      # ... and the resumed solve from the 9-step state
+        ref["resumed"] = (one.get_state(), one.get_iters(), out.read(dt).copy(), one.reduce())
+    it200 = ref[200][1][0]
+    assert it200.max() >= 3 * np.median(it200), (it200.max(), np.median(it200))      # the family really has stragglers
+    for rounds, lanes in ((0, 24), (2, 24), (5, 8), (8, 48), (3, 1)):
+        with rp.Batch(n) as b, DeviceBuffer(32 * n, fill=0xff) as out:
+            b.set_params(handoff_rounds=rounds, handoff_lanes=lanes)
+            b.bind_solution(out.ptr)
+            for cap in (200, 9):
+                b.set_state(st0)
+                b.solve(1e-8, cap, 0)
+                st, (it, status), rec, red = b.get_state(), b.get_iters(), out.read(dt), b.reduce()
+                assert np.array_equal(st.view(np.uint64), ref[cap][0].view(np.uint64)), (rounds, lanes, cap, int((st.view(np.uint64) != ref[cap][0].view(np.uint64)).any(axis=1).sum()))
+                assert np.array_equal(it, ref[cap][1][0]) and np.array_equal(status, ref[cap][1][1]), (rounds, lanes, cap)
+                assert np.array_equal(rec.view(np.uint8), ref[cap][2].view(np.uint8)) and repr(red) == repr(ref[cap][3]), (rounds, lanes, cap)
+            b.solve(1e-8, 200, 0)
+            st, (it, status), rec, red = b.get_state(), b.get_iters(), out.read(dt), b.reduce()
+            assert np.array_equal(st.view(np.uint64), ref["resumed"][0].view(np.uint64)) and np.array_equal(it, ref["resumed"][1][0]) and np.array_equal(status, ref["resumed"][1][1])
+            assert np.array_equal(rec.view(np.uint8), ref["resumed"][2].view(np.uint8)) and repr(red) == repr(ref["resumed"][3])
+    # the answers themselves: iteration counts and (v, t0, t1) against the oracle
+    aos = st0.copy()
+    it_o = np.asarray(oracle.batch_solve_gated(3, aos, 1e-8, 200)[0])
+    # ... for the starts INSIDE the feasible set.  (A start outside it is outside the parity statement: the reference makes no progress from
+    # one, 100 halvings and a frozen state -- test_infeasible_start_is_frozen_and_flagged -- unless its singular KKT system happens to
+    # yield a direction of ~1e30, which a step length of 2^-100 turns into a real move: noise that no two solvers share.  A start ON a
+    # limit is a tie of the first feasibility test.)  |a| <= L (1 - 1e-9) at all four ends, from the spline formulas of SURVEY 8a:
+    v1, t0, t1, x0, x1, x2 = st0[:, 0], st0[:, 1], st0[:, 2], st0[:, 11], st0[:, 13], st0[:, 14]
+    acc = np.stack([(6 * (x1 - x0) / t0 - 2 * v1) / t0, (-6 * (x1 - x0) / t0 + 4 * v1) / t0,
+                    (6 * (x2 - x1) / t1 - 4 * v1) / t1, (-6 * (x2 - x1) / t1 + 2 * v1) / t1], axis=1)
+    keep = np.max(np.abs(acc), axis=1) <= 100.0 * (1 - 1e-9)
+    keep &= it_o <= 80      # (and for the problems that do not STALL: a stalled trajectory -- dozens of halvings per step for a hundred steps -- is noise-driven)
+    assert keep.sum() > n // 2
+    ok = keep_mask(keep.sum(), certify_iteration_counts(oracle, 3, st0[keep], it200[keep], it_o[keep], 1e-8, max_ties=16))
+    done = ok & (it_o[keep] < 200)
+    assert serr(ref[200][0][keep][done, :3], aos[keep][done, :3]) < 1e-9
+
+
+def test_idle_lane_steps_of_states_entered_through_set_state(oracle):
+    # VERDICT r5 next 4, the measurement it asks for first: batches entered through rp_batch_set_state with the nudges the reference's keys
+    # make (durations +0.1 / +1, onedpath_ip.cpp:280-324), multipliers other than 1, and the three position distributions mixed and
+    # shuffled.  A wave holds 64 consecutive positions of the batch's internal order and runs until its slowest lane is done: idle
+    # lane-steps = 1 - sum(steps) / (64 * sum over waves of the wave's largest count), from the device's own iteration counts and slot map.
+    # The position-derived order keeps it at or below 3 % for every one of them (1.0-2.3 % at 1 Mi problems, profiles/r6_state_families.log);
+    # what it cannot know is a state whose step counts are heavy-tailed (a start outside the feasible set, per-problem multipliers over
+    # five decades): those are the business of rp_params.handoff_rounds (tests above), not of the order.
+    n = 256 * 1024
+    rng = np.random.default_rng(2)
+    base = oracle.batch_init_feasible(3, *rp.problems.generate(8675309, 0, n, rp.problems.DIST_MONOTONE))
+    fams = {"feasible start": base}
+    for d in (0.1, 1.0):
+        x = base.copy(); x[:, 1] += d; x[:, 2] += d; fams["durations +%g" % d] = x
+    for lam in (100.0, 0.01):
+        x = base.copy(); x[:, 3:11] = lam; fams["multipliers %g" % lam] = x
+    parts = [oracle.batch_init_feasible(3, *rp.problems.generate(77 + d, 0, n // 2 if d == 0 else n // 4, d)) for d in (0, 1, 2)]
+    fams["three distributions mixed"] = np.concatenate(parts)[rng.permutation(n)]
+    report = []
+    with rp.Batch(n) as b:
+        for name, st in fams.items():
+            b.set_state(st)
+            b.solve(1e-8, 200, 0)
+            it, status = b.get_iters()
+            assert np.all(status == rp.ST_CONVERGED), name
+            x = it[np.argsort(b.slot_map())].astype(np.int64).reshape(-1, 64)
+            idle = 1.0 - x.sum() / (x.max(axis=1).sum() * 64.0)
+            y = it.astype(np.int64).reshape(-1, 64)
+            report.append("%s %.3f (problem order %.3f)" % (name, idle, 1.0 - y.sum() / (y.max(axis=1).sum() * 64.0)))
+            assert idle <= 0.03, (name, idle)
+    print("idle lane-steps of the gated solve, states through set_state: " + "; ".join(report))
+
+
+@pytest.mark.parametrize("variant,dtype", [(rp.VARIANT_F4, rp.DTYPE_F64), (rp.VARIANT_F3, rp.DTYPE_F32_STATE), (rp.VARIANT_F4, rp.DTYPE_F32)])
+def test_gated_solve_in_rounds_in_the_other_variants_and_number_modes(oracle, variant, dtype):
+    # the same statement for F4 (which never converges: every problem runs into the step budget, all lanes alike) and the fp32 modes,
+    # with non-zero end velocities in half of the problems (the general kernels)
+    n = 8 * 1024 + 5
+    rng = np.random.default_rng(99)
+    p0, p1, p2 = rp.problems.generate(515, 0, n, rp.problems.DIST_MONOTONE)
+    st0 = oracle.batch_init_feasible(variant, p0, p1, p2)
+    m = 8 if variant == rp.VARIANT_F3 else 4
+    st0[:, 3:3 + m] = 10.0 ** rng.uniform(-2, 1, (n, 1))
+    st0[::2, 3 + m + 1] = 0.25                     # vel0X of every second problem
+    out = []
+    for rounds in (-1, 4):
+        with rp.Batch(n, variant, dtype) as b:
+            b.set_params(handoff_rounds=rounds, handoff_lanes=16)
+            b.set_state(st0)
+            b.solve(1e-8, 40, 0)
+            out.append((b.get_state(), b.get_iters()))
+    assert np.array_equal(out[0][0], out[1][0], equal_nan=True) and np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
+
+
 @pytest.mark.parametrize("dtype", [rp.DTYPE_F32_STATE, rp.DTYPE_F32])
 def test_f4_fused_launch_parks_its_fixed_points_and_stores_what_single_steps_store(dtype):
     # Round 6: in a fused fixed-step launch of F4 on an fp32 state a problem whose step has left its stored state bit for bit
