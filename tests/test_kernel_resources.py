@@ -32,8 +32,14 @@ def test_headline_kernels_fit_their_waves_without_scratch():
         if m and name:
             usage[name][m.group(1)] = int(m.group(2))
     # the benchmark's kernel k_solve_chunks<double, double, 3, STALL=false, ZV=true, MU=0, START=false>, its START=true twin (a
-    # fresh batch's first solve) and its fixed-step sibling k_steps_chunks<double, double, 3, ZV=true>
+    # fresh batch's first solve), its ROUNDS=true twin (round 6: the watched kernel for states that were set or nudged: same budget) and
+    # its fixed-step sibling k_steps_chunks<double, double, 3, ZV=true>
     gated = {k: v for k, v in usage.items() if "k_solve_chunksIddLi3ELb0ELb1ELi0E" in k}
+    watched = {k: v for k, v in gated.items() if "Li0ELb0ELb1EE" in k}      # <..., MU = 0, START = false, ROUNDS = true>
+    assert len(watched) == 1, sorted(gated)
+    gated = {k: v for k, v in gated.items() if k not in watched}
+    for k, v in watched.items():
+        assert v["ScratchSize [bytes/lane]"] == 0 and v["VGPRs Spill"] == 0 and v["VGPRs"] <= 128 and v["LDS Size [bytes/block]"] == 13 * 64 * 8, (k, v)
     fixed = {k: v for k, v in usage.items() if "k_steps_chunksIddLi3ELb1ELb0E" in k}      # ... with the step's start in LDS (large batches)
     small = {k: v for k, v in usage.items() if "k_steps_chunksIddLi3ELb1ELb1E" in k}      # ... in registers (batches below three waves per SIMD)
     assert len(gated) == 2 and len(fixed) == 1 and len(small) == 1, sorted(usage)
