@@ -148,6 +148,20 @@ __device__ __forceinline__ double bcast_(double x, int src)
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+#ifndef RP_FROZEN_PROOF
+#define RP_FROZEN_PROOF 1      // 0: every trial of the frozen search is evaluated (A/B builds: no decision may change)
+#endif
+#ifndef RP_FROZEN_MASKS
+#define RP_FROZEN_MASKS 1     // the fixed-step kernels' feasibility loop (newton_step_inplace<FROZEN>) keeps its per-lane flag as a 64-bit lane mask in scalar
+                              // registers (0: the bool form, A/B).  Measured at 65,536 x 50 (profiles/r6_tuning.md): 289 -> 246 scalar instructions per
+                              // post-convergence wave-step, 0.200 -> 0.194 ms.  The same treatment of the residual loop costs 40-70 VGPRs (spills at every
+                              // occupancy) whichever way the mask becomes a predicate again, and a wave-uniform form of the frozen search trades its 17
+                              // scalar instructions per trip for 5 vector ones and is slower: neither is in the source.
+#endif
+// lane mask <-> lane predicate without a vector instruction (the mask must be wave-uniform, which a ballot's result is)
+__device__ __forceinline__ unsigned long long ballot_(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ bool in_mask_(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // Solver constants in the compute type (rp_params, include/rp_batch.h).
 template <typename T> struct KParams {
     T limit;        // L
@@ -885,7 +899,10 @@ __device__ __forceinline__ void direction_split(const P &k, const KParams<T> &kp
 // negative, and inside it the WAVE skips multiplier i when it would in none of its lanes (one compare and a scalar branch
 // instead of two multiplications, a compare and four selects).  A skipped multiplier has ratio >= 1 and could not have
 // changed the minimum below 1; a -0 or a NaN with its sign bit set passes the screens and loses the comparison.
-template <typename T, int NC>
+// WAVE_SCREEN = false (RP_FROZEN_BF, the fixed-step kernels' build switch): behind the lane screen every multiplier is compared, no
+// per-multiplier wave votes -- eight ballots, scalar compares and branches that a lone wave in the post-convergence regime (where the
+// directions are rounding noise and sign bits are set at random, so the votes skip little) pays an issue slot each for.
+template <typename T, int NC, bool WAVE_SCREEN = true>
 __device__ __forceinline__ T boundary_fraction(const KParams<T> &kp, const T (&lam)[NC], const T (&dl)[NC], const T (&sg)[NC], unsigned suspect)
 {
     T s = kp.boundary;
@@ -896,6 +913,18 @@ __device__ __forceinline__ T boundary_fraction(const KParams<T> &kp, const T (&l
         unsigned bits;
         if constexpr (NC == 8) bits = or3_(or3_(hi[0], hi[1], hi[2]), or3_(hi[3], hi[4], hi[5]), or3_(hi[6], hi[7], suspect));
         else bits = or3_(or3_(hi[0], hi[1], hi[2]), hi[3], suspect);
+        if constexpr (!WAVE_SCREEN) {
+            if ((int)bits < 0) {
+                T nb = T(1), db = T(-1);
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const bool take = lam[i] * db > nb * dl[i];
+                    nb = take ? lam[i] : nb;
+                    db = take ? dl[i] : db;
+                }
+                s = min_(nb * rcp1_(-db), T(1)) * kp.boundary;
+            }
+        } else
         if ((int)bits < 0) {
             const bool every = __builtin_amdgcn_ballot_w64((int)suspect < 0) != 0ull;      // a pair product not positive somewhere in the wave: no screen
             T nb = T(1), db = T(-1);
@@ -1607,7 +1636,11 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
 #pragma unroll
     for (int i = 0; i < NC; ++i) bk.put(3 + i, lam[i]);
 
-    T s = boundary_fraction<T, NC>(kp, lam, dl, sg, suspect);         // onedpath_ip.cpp:903-915
+#ifndef RP_FROZEN_BF
+#define RP_FROZEN_BF 1      // the fixed-step kernels (FROZEN) take the boundary fraction without the per-multiplier wave votes (0: with them, A/B): 0.194 -> 0.183 ms
+                            // at 65,536 x 50 and 0.0203 -> 0.0185 ms at 65,536 x 12 -- a lone wave pays an issue slot for every vote, compare and branch
+#endif
+    T s = boundary_fraction<T, NC, !(FROZEN && RP_FROZEN_BF != 0)>(kp, lam, dl, sg, suspect);         // onedpath_ip.cpp:903-915
 
     // -- backtrack until primal feasible (onedpath_ip.cpp:919-928); a trial is formed where s is set --
     Acc<T> et;
@@ -1616,7 +1649,44 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
     v = fma_(dxv, s, v);
     t0 = fma_(dx0, s, t0);
     t1 = fma_(dx1, s, t1);
-    {
+    if constexpr (FROZEN && RP_FROZEN_MASKS != 0) {
+        // The same loop with its per-lane flags (the trial has become x: at_x) as LANE MASKS in scalar registers: a flag carried round a
+        // loop as a bool comes back as a select and a compare every time it is tested or merged; a mask is combined by scalar and / or
+        // and becomes a predicate again at no cost (in_mask_).  Same decisions per lane.
+        bool used = VARIANT == 4;
+        unsigned long long atx_m = 0ull;
+        for (;;) {
+            accel_values_u(k, v, t0, t1, et, xt);
+            const unsigned long long bad_m = ballot_(!all_satisfied<T, VARIANT>(et, L));
+            if (bad_m == 0ull) break;
+            const unsigned long long go_m = bad_m & ballot_(it < kp.max_bt);      // (out of halvings: the reference goes on with an s it has not tested)
+            if (go_m == 0ull) break;
+            used = true;
+            const unsigned long long jump_m = go_m & atx_m, step_m = go_m & ~atx_m;
+            if (jump_m != 0ull) {
+                if (in_mask_(jump_m)) {      // x itself fails the test by a rounding and every smaller s gives x again: the remaining halvings at once
+                    if (kp.backtrack == T(0.5) && std::is_same<D, NoDiag>::value) {
+                        s = ldexp_(s, it - kp.max_bt);
+                    } else {
+                        for (int q = it; q < kp.max_bt; ++q) { s *= kp.backtrack; diag.feas(); }
+                    }
+                    it = kp.max_bt;
+                }
+            }
+            if (step_m != 0ull) {
+                if (in_mask_(step_m)) {
+                    s *= kp.backtrack;
+                    ++it;
+                    diag.feas();
+                    v = fma_(dxv, s, (T)bk.get(0));
+                    t0 = fma_(dx0, s, (T)bk.get(1));
+                    t1 = fma_(dx1, s, (T)bk.get(2));
+                }
+                atx_m |= step_m & ballot_(v == (T)bk.get(0) && t0 == (T)bk.get(1) && t1 == (T)bk.get(2));
+            }
+        }
+        if (used) { asm volatile(""); it = 0; }
+    } else {
         bool used = VARIANT == 4;      // wave-uniform: some lane has moved its counter
         [[maybe_unused]] bool at_x = false;      // FROZEN: the trial point has become x itself (and every later one will be)
         for (;;) {
@@ -1710,9 +1780,6 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                     AffineResidual<T, VARIANT> ar;
                     ar.setup(et, [&](int i) { return (T)bk.get(3 + i); }, dl, p, L);
                     const T r0a = ar(T(0));
-#ifndef RP_FROZEN_PROOF
-#define RP_FROZEN_PROOF 1      // 0: every trial of the frozen search is evaluated (A/B builds: no decision may change)
-#endif
                     if (RP_FROZEN_PROOF && kp.backtrack == T(0.5)) {
                         // the trials that fail beyond doubt, counted in closed form (AffineResidual::certain_failures)
                         int skip = ar.certain_failures(kp, r0a, s);
