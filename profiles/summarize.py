@@ -31,11 +31,11 @@ if stats_dir != "-":      # "-": the counter summaries only (collect_r4.sh folds
     shutil.copy(one(stats_dir, "*_kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_kernel_stats.csv" % tag))
     # The timed launches themselves, out of the same trace.  The per-kernel statistics above average EVERY launch of a kernel -- for the
     # benchmark's kernel that is the conditioning (which starts inside the power controller's transient), the warmup, the K timed
-    # launches, the cold-start extra ...; the K timed ones are the launches of k_solve_chunks<double, double, 3, false, true, 0, false> right
+    # launches, the cold-start extra ...; the K timed ones are the launches of k_solve_chunks<double, double, 3, false, true, 0, false, false> right
     # before the FIRST k_reduce_partial of the run (the final reduction follows them in stream order).
     try:
         rows = sorted(csv.DictReader(open(one(stats_dir, "*_kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
-        TIMED = "k_solve_chunks<double, double, 3, false, true, 0, false>"
+        TIMED = "k_solve_chunks<double, double, 3, false, true, 0, false, false>"      # <S, T, VARIANT, STALL, ZV, MU, START, ROUNDS>: the plain gated kernel
         first_reduce = next(i for i, r in enumerate(rows) if "k_reduce_partial" in r["Kernel_Name"])
         before = [r for r in rows[:first_reduce] if TIMED in r["Kernel_Name"] and int(r["Grid_Size_X"]) == N]
         bench_line = None
@@ -100,7 +100,7 @@ def alias(key, prefix, expected):
         out[key] = dict(out[hit[0]], kernel=hit[0], expected=expected)
 
 
-alias("k_solve_chunks_f3_f64", "k_solve_chunks<double, double, 3, false, true",
+alias("k_solve_chunks_f3_f64", "k_solve_chunks<double, double, 3, false, true, 0, false, false>",
       "zero-end-velocity instantiation: (14x8 + 4 + 4) B read + (11x8 + 4 + 4) B written per problem = 125.8 + 100.7 MB at n = 1,048,576")
 alias("k_newton_stream16_f3_f64", "k_newton_stream16<double, double, 3, true", "14x8 B read + 11x8 B written per problem = 117.4 + 92.3 MB")
 alias("k_newton_stream16_f4_f32", "k_newton_stream16<float, float, 4, true", "10x4 B read + 7x4 B written per problem = 41.9 + 29.4 MB")
@@ -124,7 +124,7 @@ for d in sq_dirs:
             name = short(k)
             if name.startswith(("k_newton", "k_solve", "k_steps", "k_move_toward")) and grid == real_grid(name):
                 sq.setdefault(name, {}).update(cs)
-            elif name.startswith("k_solve_chunks<double, double, 3, false, true") and grid == N // 2:
+            elif name.startswith("k_solve_chunks<double, double, 3, false, true, 0, false, false>") and grid == N // 2:
                 ident.update(cs)      # the gated kernel on 524,288 identical default problems (pmc_probe.py)
 for name, c in sq.items():
     if "SQ_WAVES" in c and "SQ_INSTS_VALU" in c:
@@ -152,7 +152,7 @@ for name, c in sq.items():
     elif name.startswith("k_steps_chunks<float, double, 4"):
         top["_flop_per_f4_step_f32state"] = f64
 # the gated kernel on identical problems: 15 steps per problem, no idle lanes
-GATED = "k_solve_chunks<double, double, 3, false, true, 0, false>"
+GATED = "k_solve_chunks<double, double, 3, false, true, 0, false, false>"
 if "SQ_INSTS_VALU_FMA_F64" in ident:
     ls = 15.0 * (N // 2)
     ident["flop_f64_per_lane_step"] = 64.0 * (2 * ident["SQ_INSTS_VALU_FMA_F64"] + ident["SQ_INSTS_VALU_MUL_F64"] + ident["SQ_INSTS_VALU_ADD_F64"]

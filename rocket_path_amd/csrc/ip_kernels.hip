@@ -306,27 +306,26 @@ __device__ __forceinline__ void run_lane(const P &pr, const KParams<T> &kp, int 
                 P pq = pr;
                 if constexpr (sizeof(T) == 8) asm volatile("" : "+v"(pq.dx0), "+v"(pq.dx1));
                 newton_step_to<T, VARIANT, P, true, AFFINE, MU, D, WAVE>(pq, kp, gap, v, t0, t1, lam, e, nv, nt0, nt1, nlam, ne, diag);
-                // value by value: round to the storage type, compare with what is stored, take it (one value in flight at a time: the
-                // kernel has no registers to hold two states side by side)
-                bool same = true;
-                auto take = [&](T &cur, T nxt) {
-                    if constexpr (sizeof(S) != sizeof(T)) {
-                        const S r = (S)nxt;
-                        same = same && __builtin_bit_cast(unsigned, r) == __builtin_bit_cast(unsigned, (S)cur);      // (cur holds a value of S exactly)
-                        cur = (T)r;
-                    } else {
-                        same = same && bits(nxt) == bits(cur);
-                        cur = nxt;
+                // Round to the storage type and take the new state; behind a screen on vel1 alone (a moving iterate never repeats its velocity
+                // bit for bit: one conversion and one compare per step) the whole state is compared with what was stored, value by value
+                // before it is overwritten (the kernel has no registers to hold two states side by side).
+                bool same = false;
+                auto put = [&](T &cur, T nxt) { if constexpr (sizeof(S) != sizeof(T)) cur = (T)(S)nxt; else cur = nxt; };
+                auto sbits = [](T x) { if constexpr (sizeof(S) == 4) return __builtin_bit_cast(unsigned, (S)x); else return __builtin_bit_cast(unsigned long long, (S)x); };      // (of the value as stored)
+                const bool v_same = sbits(nv) == sbits(v);
+                if (__builtin_amdgcn_ballot_w64(v_same) != 0ull) {
+                    same = v_same && sbits(nt0) == sbits(t0) && sbits(nt1) == sbits(t1);
+#pragma unroll
+                    for (int c = 0; c < NCc; ++c) same = same && sbits(nlam[c]) == sbits(lam[c]);
+                    if constexpr (sizeof(S) == sizeof(T)) {      // (otherwise evaluate() below rebuilds the carried evaluation from the rounded state: a function of it)
+                        same = same && bits(ne.r0) == bits(e.r0) && bits(ne.r1) == bits(e.r1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) same = same && bits(ne.a[j]) == bits(e.a[j]);
                     }
-                };
-                take(v, nv); take(t0, nt0); take(t1, nt1);
-#pragma unroll
-                for (int c = 0; c < NCc; ++c) take(lam[c], nlam[c]);
-                if constexpr (sizeof(S) == sizeof(T)) {      // (otherwise evaluate() below rebuilds the carried evaluation from the rounded state: a function of it)
-                    same = same && bits(ne.r0) == bits(e.r0) && bits(ne.r1) == bits(e.r1);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) same = same && bits(ne.a[j]) == bits(e.a[j]);
                 }
+                put(v, nv); put(t0, nt0); put(t1, nt1);
+#pragma unroll
+                for (int c = 0; c < NCc; ++c) put(lam[c], nlam[c]);
                 parked = same;
                 if constexpr (sizeof(S) != sizeof(T)) evaluate();      // the carried evaluation belongs to the unrounded point
                 else e = ne;
