@@ -237,6 +237,14 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, rehearsal=args.rehearse_on_one_gpu))
 
+    # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless the environment says otherwise, and two
+    # streams that land on one queue serialise.  This process owns more than that (the timed batches' stream, the pipeline's two, the
+    # two-stream extras', torch's): with 4 queues the two streams of `end_to_end`'s rp_pipeline can end up sharing one (measured on one box with
+    # four user streams alive: 73 G steps/s against 91 G with 8 queues, profiles/r6_hw_queues.log).  An application's setting, made here by the
+    # application before anything initialises HIP -- the library itself neither reads nor writes the environment; the headline (one stream) is
+    # not affected either way.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
     import torch
     import torch.distributed as dist
 
@@ -423,6 +431,7 @@ def main():
         "ranks_in_process_group": dist.get_world_size() if grouped else 1,      # what RCCL (torch.distributed "nccl") saw
         "process_group_backend": (dist.get_backend() if grouped else None),    # "nccl" = RCCL; None: no group was created (N = 1 without --force-process-group)
         "self_launched": bool(os.environ.get("RP_BENCH_SELF_LAUNCHED")),
+        "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),      # set to 8 by this program unless the caller's environment had a value (see main)
         "steps": K,
         "warmup": W,
         # everything launched between the last idle moment and the timed region: the conditioning solves + the W warmup passes the driver asked for

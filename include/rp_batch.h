@@ -288,6 +288,10 @@ RP_API int rp_batch_slot_map(rp_batch *b, uint32_t *slot_of_problem);
  *                  on the device.  The arrays must stay untouched until the job's scheduling pass has read them:
  *                  rp_pipeline_stream_wait(job, 0, s) makes stream s wait for exactly that, rp_pipeline_wait(job) the host.
  *   d_out          n rp_solution records in problem order (32-byte aligned; NULL: none -- read the batch through rp_pipeline_batch)
+ * (An application note, not something the library does: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware
+ * queues -- 4 by default -- and streams that share a queue serialise.  A process that already owns two or three streams of its own should
+ * export GPU_MAX_HW_QUEUES=8 before its first HIP call, or the pipeline's two streams may come to share a queue: 73 against 91 G Newton
+ * steps/s on one box, profiles/r6_hw_queues.log.  bench.py does so.)
  *   job            receives the job's number (0, 1, 2, ...); a slot is reused every `depth` jobs, in stream order -- the previous
  *                  job of the slot has finished on the device before the new one touches the batch; its d_out is the caller's to
  *                  have consumed by then. */

@@ -9,13 +9,21 @@ import rocket_path_amd as rp
 from hip_util import DeviceBuffer
 N = int(os.environ.get("N", 1 << 20)); JOBS = 120
 q = rp.problems.generate(12345, 0, N, 0)
-pos = DeviceBuffer(3 * 8 * N); pos.write(np.stack(q))
-outs = [DeviceBuffer(32 * N) for _ in range(4)]
-ptrs = (pos.ptr, pos.ptr + 8 * N, pos.ptr + 16 * N)
+# COLD=1 (default): every job reads its positions from a buffer of its own -- 16 of them, 400 MB, more than the 256 MB Infinity Cache holds -- as a
+# caller's fresh inputs would arrive; COLD=0: all jobs read ONE 24 MB buffer (cache-resident after the first job: flatters the scheduling pass)
+COLD = os.environ.get("COLD", "1") != "0"
+NPOS = 16 if COLD else 1
+poss = []
+for _ in range(NPOS):
+    d = DeviceBuffer(3 * 8 * N); d.write(np.stack(q)); poss.append(d)
+outs = [DeviceBuffer(32 * N) for _ in range(8)]
+ptrs = (poss[0].ptr, poss[0].ptr + 8 * N, poss[0].ptr + 16 * N)
+print("positions:", "a buffer per job (16 x 24 MB, cold)" if COLD else "one 24 MB buffer for all jobs (cache-resident)")
 
 def burst(pipe, jobs):
     for j in range(jobs):
-        pipe.submit(*ptrs, d_out=outs[j % 4].ptr)
+        d = poss[j % NPOS]
+        pipe.submit(d.ptr, d.ptr + 8 * N, d.ptr + 16 * N, d_out=outs[j % 8].ptr)
     pipe.wait()
 
 res = {}
