@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A short rp_pipeline run for `rocprofv3 --kernel-trace`: MODE = inline | prep | priority, 2 streams, 40 jobs after 80 untimed ones."""
 import os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises: streams that share one of the default 4 hardware queues serialise (profiles/r6_hw_queues.log)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
