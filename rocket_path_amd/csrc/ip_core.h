@@ -1053,25 +1053,25 @@ template <typename T, int VARIANT> struct AffineResidual {
     template <class D>
     __device__ __forceinline__ bool search(const KParams<T> &kp, T r0, T &s, int &it, D &diag) const
     {
-        constexpr int W = 2;      // measured at 65,536 problems x 50 steps: W = 1 0.545 ms, W = 2 0.332 ms, W = 4 0.352 ms
+        // Two step lengths per trip (measured at 65,536 problems x 50 steps: one 0.545 ms, two 0.332 ms, four 0.352 ms), written out
+        // BRANCH-FREE (round 6): which of the two trials is the first to pass, how many halvings that makes and the next step length are
+        // selects on two comparisons -- as a loop over q with `q < valid && ...` the compiler nested two exec-mask regions per trip, eight
+        // scalar instructions and two branches that a lone wave pays an issue slot each for (profiles/r6_tuning.md).
+#ifdef RP_SEARCH_BRANCHY      // A/B: the round-5 form of the trip
+        constexpr int W = 2;
         while (it < kp.max_bt) {
             T sk[W], rn[W];
             sk[0] = s;
-#pragma unroll
             for (int q = 1; q < W; ++q) sk[q] = sk[q - 1] * kp.backtrack;
-#pragma unroll
             for (int q = 0; q < W; ++q) rn[q] = (*this)(sk[q]);
-#pragma unroll
-            for (int q = 0; q < W; ++q) asm volatile("" : "+v"(rn[q]));      // (opaque: or the compiler sinks the later evaluations behind the test of the first and serialises them)
-            const int valid = (kp.max_bt - it < W) ? kp.max_bt - it : W;      // trials the reference would still make
-            int first = W;                                                    // first accepted trial of this trip
-#pragma unroll
+            for (int q = 0; q < W; ++q) asm volatile("" : "+v"(rn[q]));
+            const int valid = (kp.max_bt - it < W) ? kp.max_bt - it : W;
+            int first = W;
             for (int q = W - 1; q >= 0; --q)
                 if (q < valid && rn[q] <= r0 * (T(1) - kp.armijo * sk[q])) first = q;
             const bool got = first < W;
             const int halved = got ? first : valid;
-            T snew = sk[W - 1] * kp.backtrack;                                // all W failed
-#pragma unroll
+            T snew = sk[W - 1] * kp.backtrack;
             for (int q = W - 1; q >= 0; --q)
                 if (halved == q) snew = sk[q];
             s = snew;
@@ -1079,6 +1079,23 @@ template <typename T, int VARIANT> struct AffineResidual {
                 for (int q = 0; q < halved; ++q) diag.resid();
             it += halved;
             if (got) return true;
+        }
+        return false;
+#endif
+        while (it < kp.max_bt) {
+            const T s0 = s, s1 = s * kp.backtrack;
+            T r0v = (*this)(s0), r1v = (*this)(s1);
+            asm volatile("" : "+v"(r0v), "+v"(r1v));      // (opaque: or the compiler sinks the second evaluation behind the test of the first and serialises them)
+            const int left = kp.max_bt - it;              // trials the reference would still make: >= 1 here
+            const bool ok0 = r0v <= r0 * (T(1) - kp.armijo * s0);
+            const bool ok1 = ((int)(left > 1) & (int)(r1v <= r0 * (T(1) - kp.armijo * s1))) != 0;
+            const int none = left < 2 ? left : 2;         // halvings when neither passes
+            const int halved = ok0 ? 0 : ok1 ? 1 : none;
+            s = ok0 ? s0 : (ok1 | (left < 2)) ? s1 : s1 * kp.backtrack;
+            if constexpr (!std::is_same<D, NoDiag>::value)
+                for (int q = 0; q < halved; ++q) diag.resid();
+            it += halved;
+            if (ok0 | ok1) return true;
         }
         return false;
     }
