@@ -1630,6 +1630,14 @@ template <typename T, int N> struct RegColumn {
 // mask; a lane whose trial has passed simply re-evaluates its unchanged trial (same values, the instructions issue for the wave
 // anyway) while others retry.  The halving counter `it` is touched only where a trial fails: it enters every loop as zero and is
 // put back to zero behind a wave-uniform branch when some lane used it.
+#ifndef RP_USED_INT
+#define RP_USED_INT 1      // the wave-uniform "some lane moved its halving counter" flag of the in-place step's loops as an int (0: a bool, A/B)
+#endif
+#if RP_USED_INT
+typedef int used_t;
+#else
+typedef bool used_t;
+#endif
 template <typename T, int VARIANT, class P, bool FROZEN = false, class D = NoDiag, class BK = LdsColumn<T>>
 __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T> &kp, T gap, T &v, T &t0, T &t1, T (&lam)[CMap<VARIANT>::NC],
                                                     AccCarry<T, true, true> &c, BK &bk, int &it, D &diag)
@@ -1670,7 +1678,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
         // The same loop with its per-lane flags (the trial has become x: at_x) as LANE MASKS in scalar registers: a flag carried round a
         // loop as a bool comes back as a select and a compare every time it is tested or merged; a mask is combined by scalar and / or
         // and becomes a predicate again at no cost (in_mask_).  Same decisions per lane.
-        bool used = VARIANT == 4;
+        used_t used = VARIANT == 4;
         unsigned long long atx_m = 0ull;
         for (;;) {
             accel_values_u(k, v, t0, t1, et, xt);
@@ -1678,7 +1686,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
             if (bad_m == 0ull) break;
             const unsigned long long go_m = bad_m & ballot_(it < kp.max_bt);      // (out of halvings: the reference goes on with an s it has not tested)
             if (go_m == 0ull) break;
-            used = true;
+            used = 1;
             const unsigned long long jump_m = go_m & atx_m, step_m = go_m & ~atx_m;
             if (jump_m != 0ull) {
                 if (in_mask_(jump_m)) {      // x itself fails the test by a rounding and every smaller s gives x again: the remaining halvings at once
@@ -1702,9 +1710,9 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 atx_m |= step_m & ballot_(v == (T)bk.get(0) && t0 == (T)bk.get(1) && t1 == (T)bk.get(2));
             }
         }
-        if (used) { asm volatile(""); it = 0; }
+        if (used != 0) { asm volatile(""); it = 0; }
     } else {
-        bool used = VARIANT == 4;      // wave-uniform: some lane has moved its counter
+        used_t used = VARIANT == 4;      // wave-uniform: some lane has moved its counter
         [[maybe_unused]] bool at_x = false;      // FROZEN: the trial point has become x itself (and every later one will be)
         for (;;) {
             accel_values_u(k, v, t0, t1, et, xt);
@@ -1714,7 +1722,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
             // (out of halvings: the reference goes on with an s it has not tested)
             const bool room = it < kp.max_bt;
             if ((any_bad & __builtin_amdgcn_ballot_w64(room)) == 0ull) break;
-            used = true;
+            used = 1;
             if (bad && room) {
                 if (FROZEN && at_x) {
                     // x itself fails the test by a rounding (the residual loop accepts points the feasibility loop never saw, as the
@@ -1738,15 +1746,24 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 }
             }
         }
-        if (used) { asm volatile(""); it = 0; }      // (a branch, not a select: the common path does not touch the counter)
+        if (used != 0) { asm volatile(""); it = 0; }      // (a branch, not a select: the common path does not touch the counter)
     }
     // -- backtrack until the residual decreases (onedpath_ip.cpp:932-945), and take the step (:949-952): the trial that ends
     // the loop -- accepted, or the last s, which the reference takes untested -- is the new state, its sums the next step's --
 #pragma unroll
     for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
     {
-        bool used = false;
+        used_t used = 0;
+#ifndef RP_FROZEN_INTFLAG
+#define RP_FROZEN_INTFLAG 1      // the flag lives in a vector register as 0 / 1 and every test of it is a FRESH compare (0: a bool, A/B) -- a bool carried round
+                                 // the loop is merged by three scalar mask operations per trip and comes back through v_cndmask / v_cmp at each ballot:
+                                 // 230 -> 187 scalar instructions per post-convergence wave-step of a lone wave (profiles/r6_tuning.md)
+#endif
+#if RP_FROZEN_INTFLAG
+        [[maybe_unused]] int frozen = 0;            // FROZEN: the trial point has become bitwise x (and stays so: s only shrinks)
+#else
         [[maybe_unused]] bool frozen = false;      // FROZEN: the trial point has become bitwise x (and stays so: s only shrinks)
+#endif
         for (;;) {
             accel_grads_u<T, P>(et, xt);
             residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);      // (r0n and the direction have taken what they needed from c)
@@ -1756,10 +1773,10 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
             const unsigned long long any_bad = __builtin_amdgcn_ballot_w64(bad);
             if (any_bad == 0ull) break;
             const bool room = it < kp.max_bt;
-            const bool again = bad && room && !(FROZEN && frozen);
+            const bool again = bad && room && !(FROZEN && frozen != 0);
             if constexpr (FROZEN) { if (__builtin_amdgcn_ballot_w64(again) == 0ull) break; }
             else { if ((any_bad & __builtin_amdgcn_ballot_w64(room)) == 0ull) break; }
-            used = true;
+            used = 1;
             if (again) {
                 s *= kp.backtrack;
                 ++it;
@@ -1772,7 +1789,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 v = fma_(dxv, s, x0);
                 t0 = fma_(dx0, s, x1);
                 t1 = fma_(dx1, s, x2);
-                if constexpr (FROZEN) frozen = v == x0 && t0 == x1 && t1 == x2;
+                if constexpr (FROZEN) frozen = (v == x0 && t0 == x1 && t1 == x2) ? 1 : 0;
                 accel_values_u(k, v, t0, t1, et, xt, kdx0, kdx1);
 #pragma unroll
                 for (int i = 0; i < NC; ++i) lam[i] = fma_(dl[i], s, lam[i]);
@@ -1780,7 +1797,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
             // FROZEN: when every lane that is still searching has frozen, the affine search below takes over at once (its first
             // candidate is the trial just formed); the sums of such a trial are only wanted for the one the search ends on
             if constexpr (FROZEN) {
-                if (__builtin_amdgcn_ballot_w64(again && !frozen) == 0ull) break;
+                if (__builtin_amdgcn_ballot_w64(again && frozen == 0) == 0ull) break;
             }
         }
         if constexpr (FROZEN) {
@@ -1790,9 +1807,9 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
             // 27 instructions per halving, two step lengths per trip) against the value the same pieces give at s = 0 -- the
             // regime's own, self-consistent evaluation, as the reference's loop is: it ends where s r' drops below half an
             // ulp of r.  The trial it ends on is the new state; its sums, in the carried form, are the next step's.
-            if (__builtin_amdgcn_ballot_w64(frozen) != 0ull) {
-                used = true;
-                if (frozen) {
+            if (__builtin_amdgcn_ballot_w64(frozen != 0) != 0ull) {
+                used = 1;
+                if (frozen != 0) {
                     accel_grads_u<T, P>(et, xt);      // (the loop above may have been left before it came round to this trial)
                     AffineResidual<T, VARIANT> ar;
                     ar.setup(et, [&](int i) { return (T)bk.get(3 + i); }, dl, p, L);
@@ -1815,7 +1832,7 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                 }
             }
         }
-        if (used) { asm volatile(""); it = 0; }
+        if (used != 0) { asm volatile(""); it = 0; }
     }
     c.r0 = et.r0; c.r1 = et.r1;
     c.x = xt;
