@@ -1757,13 +1757,12 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
 #ifndef RP_FROZEN_INTFLAG
 #define RP_FROZEN_INTFLAG 1      // the flag lives in a vector register as 0 / 1 and every test of it is a FRESH compare (0: a bool, A/B) -- a bool carried round
                                  // the loop is merged by three scalar mask operations per trip and comes back through v_cndmask / v_cmp at each ballot:
-                                 // 230 -> 187 scalar instructions per post-convergence wave-step of a lone wave (profiles/r6_tuning.md)
+                                 // 230 -> 187 scalar instructions per post-convergence wave-step of a lone wave (profiles/r6_tuning.md).  Where the step's
+                                 // start waits in registers only (the small-batch kernels, which are the ones a lone wave runs): the LDS-column kernels sit
+                                 // at 128 VGPRs for their fourth wave and have none to spare for it
 #endif
-#if RP_FROZEN_INTFLAG
-        [[maybe_unused]] int frozen = 0;            // FROZEN: the trial point has become bitwise x (and stays so: s only shrinks)
-#else
-        [[maybe_unused]] bool frozen = false;      // FROZEN: the trial point has become bitwise x (and stays so: s only shrinks)
-#endif
+        constexpr bool kIntFlag = RP_FROZEN_INTFLAG != 0 && !std::is_same<BK, LdsColumn<T>>::value;
+        [[maybe_unused]] std::conditional_t<kIntFlag, int, bool> frozen = 0;      // FROZEN: the trial point has become bitwise x (and stays so: s only shrinks)
         for (;;) {
             accel_grads_u<T, P>(et, xt);
             residual_sums<T, VARIANT, false>(et, lam, dl, T(0), L, c.X, c.Q1, c.Q2, c.cm, c.cp);      // (r0n and the direction have taken what they needed from c)
