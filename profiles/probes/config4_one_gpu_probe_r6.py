@@ -4,8 +4,8 @@ passes from an idle chip and read 74 G where the steady batch-size log read 103.
 for >= 60 ms before its clock starts and then timed over several passes: the 8 shards of 1,048,576 (what each of 8 ranks would run) one after
 the other on one stream; the same 8 shards as 8 jobs of an rp_pipeline on two streams; ONE batch of 8,388,608.  From bare positions, with
 the summary reduction of every shard; the summaries of the three forms must agree."""
-import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises: streams that share one of the default 4 hardware queues serialise (profiles/r6_hw_queues.log), time
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises: streams that share one of the default 4 hardware queues serialise (profiles/r6_hw_queues.log)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """rp_pipeline arrangements (streams, where the scheduling pass runs) at steady clocks: ms per job of "positions in -> solutions out" at
 1 Mi problems, wall clock over a burst of jobs after a conditioning burst; the one-stream solve-only figure measured the same way beside it."""
-import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises: streams that share one of the default 4 hardware queues serialise (profiles/r6_hw_queues.log), time
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises: streams that share one of the default 4 hardware queues serialise (profiles/r6_hw_queues.log)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
