@@ -1707,7 +1707,13 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
                     t0 = fma_(dx0, s, (T)bk.get(1));
                     t1 = fma_(dx1, s, (T)bk.get(2));
                 }
-                atx_m |= step_m & ballot_(v == (T)bk.get(0) && t0 == (T)bk.get(1) && t1 == (T)bk.get(2));
+                // (one ballot per comparison, the masks combined as integers: a ballot of `a && b && c` is lowered through a select and a
+                // compare -- two vector instructions to turn three lane masks into one)
+#ifndef RP_SPLIT_BALLOTS
+#define RP_SPLIT_BALLOTS 1      // 0: one ballot of the conjunction (A/B)
+#endif
+                if constexpr (RP_SPLIT_BALLOTS != 0) atx_m |= step_m & ballot_(v == (T)bk.get(0)) & ballot_(t0 == (T)bk.get(1)) & ballot_(t1 == (T)bk.get(2));
+                else atx_m |= step_m & ballot_(v == (T)bk.get(0) && t0 == (T)bk.get(1) && t1 == (T)bk.get(2));
             }
         }
         if (used != 0) { asm volatile(""); it = 0; }
@@ -1773,8 +1779,12 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
             if (any_bad == 0ull) break;
             const bool room = it < kp.max_bt;
             const bool again = bad && room && !(FROZEN && frozen != 0);
-            if constexpr (FROZEN) { if (__builtin_amdgcn_ballot_w64(again) == 0ull) break; }
-            else { if ((any_bad & __builtin_amdgcn_ballot_w64(room)) == 0ull) break; }
+            [[maybe_unused]] unsigned long long again_m = 0ull;      // = ballot(again), from one ballot per comparison (see the feasibility loop)
+            if constexpr (FROZEN) {
+                if constexpr (RP_SPLIT_BALLOTS != 0) again_m = any_bad & __builtin_amdgcn_ballot_w64(room) & __builtin_amdgcn_ballot_w64(frozen == 0);
+                else again_m = __builtin_amdgcn_ballot_w64(again);
+                if (again_m == 0ull) break;
+            } else { if ((any_bad & __builtin_amdgcn_ballot_w64(room)) == 0ull) break; }
             used = 1;
             if (again) {
                 s *= kp.backtrack;
@@ -1796,7 +1806,8 @@ __device__ __forceinline__ void newton_step_inplace(const P &k, const KParams<T>
             // FROZEN: when every lane that is still searching has frozen, the affine search below takes over at once (its first
             // candidate is the trial just formed); the sums of such a trial are only wanted for the one the search ends on
             if constexpr (FROZEN) {
-                if (__builtin_amdgcn_ballot_w64(again && frozen == 0) == 0ull) break;
+                if constexpr (RP_SPLIT_BALLOTS != 0) { if ((again_m & __builtin_amdgcn_ballot_w64(frozen == 0)) == 0ull) break; }
+                else { if (__builtin_amdgcn_ballot_w64(again && frozen == 0) == 0ull) break; }
             }
         }
         if constexpr (FROZEN) {
