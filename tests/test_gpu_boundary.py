@@ -704,6 +704,51 @@ def test_pipeline_results_are_the_one_stream_paths_bit_for_bit(oracle):
             x.close()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 2047, 2048, 2049, 4097])
+def test_pipeline_on_batches_around_the_tile_and_wave_edges(n):
+    # the one-wave scheduling kernels walk tiles of 2,048 problems in chunks of 8 per lane (schedule.hip, slim::): a single problem, one
+    # short of / exactly / one past a wave and a tile.  Same order as the 256-thread form, same records as the one-stream path.
+    from hip_util import DeviceBuffer
+    dt = np.dtype(rp.capi.SOLUTION_FIELDS)
+    q = rp.problems.generate(5150 + n, 0, n, rp.problems.DIST_MONOTONE)
+    with DeviceBuffer(3 * 8 * n) as pos, DeviceBuffer(32 * n, fill=0xff) as out, DeviceBuffer(32 * n, fill=0xff) as want:
+        pos.write(np.stack(q))
+        with rp.Batch(n) as plain:
+            plain.bind_solution(want.ptr)
+            plain.set_problems(*q)
+            plain.solve(1e-8, 200, 0)
+            order = plain.slot_map()
+            expect = want.read(dt).copy()
+        assert np.array_equal(np.sort(order), np.arange(n))
+        with rp.Pipeline(n, depth=2, n_streams=2) as pipe:
+            for _ in range(3):                                   # every slot, and the first one twice
+                j = pipe.submit(pos.ptr, pos.ptr + 8 * n, pos.ptr + 16 * n, d_out=out.ptr)
+            pipe.wait()
+            assert np.array_equal(pipe.batch(j).slot_map(), order)
+            assert np.array_equal(out.read(dt).view(np.uint8), expect.view(np.uint8))
+    assert np.all(expect["status"] == rp.ST_CONVERGED)
+
+
+def test_pipeline_of_f4_batches_in_the_fp32_state_mode():
+    # F4 never converges (README.md:34): every problem leaves at the step cap; the records are the one-stream path's.
+    from hip_util import DeviceBuffer
+    n, cap = 8192 + 5, 12
+    dt = np.dtype(rp.capi.SOLUTION_FIELDS)
+    q = rp.problems.generate(77, 0, n, rp.problems.DIST_MONOTONE)
+    with DeviceBuffer(3 * 8 * n) as pos, DeviceBuffer(32 * n, fill=0xff) as out, DeviceBuffer(32 * n, fill=0xff) as want:
+        pos.write(np.stack(q))
+        with rp.Batch(n, rp.VARIANT_F4, rp.DTYPE_F32_STATE) as plain:
+            plain.bind_solution(want.ptr)
+            plain.set_problems(*q)
+            plain.solve(1e-8, cap, 0)
+            expect = want.read(dt).copy()
+        with rp.Pipeline(n, rp.VARIANT_F4, rp.DTYPE_F32_STATE, depth=2, n_streams=2) as pipe:
+            pipe.submit(pos.ptr, pos.ptr + 8 * n, pos.ptr + 16 * n, d_out=out.ptr, max_iter=cap)
+            pipe.wait()
+        assert np.array_equal(out.read(dt).view(np.uint8), expect.view(np.uint8))
+    assert np.mean(expect["iters"] == cap) > 0.99 and np.mean((expect["status"] & rp.ST_MAXITER) != 0) > 0.99
+
+
 def test_pipeline_waits_for_inputs_produced_on_another_stream_and_takes_params():
     # inputs_stream: the positions are written by work queued on the caller's stream (here: a batch's own stream doing a long solve
     # first, then a device-to-device copy into the position buffer); the job must not read them before.  And rp_pipeline_set_params
