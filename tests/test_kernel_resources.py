@@ -67,3 +67,31 @@ def test_headline_kernels_fit_their_waves_without_scratch():
             assert v.get("VGPRs Spill", 0) == 0, (k, v)
             checked += 1
     assert checked > 60
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_one_wave_scheduling_kernels_fit_where_one_solve_wave_has_left():
+    # schedule.hip, slim::: beside a resident solve (16 single-wave blocks of 128 VGPRs and 6.5 KB of LDS per CU) a block gets in only
+    # if it needs no more than ONE retiring solve wave leaves behind in registers -- 128 VGPRs -- and its LDS fits beside the other 15
+    # columns (160 KB - 15 x 6.5 KB = 62 KB free)
+    src = os.path.join(ROOT, "rocket_path_amd", "csrc", "schedule.hip")
+    r = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.devnull, src],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "warning" not in r.stderr, r.stderr[-2000:]
+    usage, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1)] = int(m.group(2))
+    slim = {k: v for k, v in usage.items() if "4slim" in k}
+    assert len(slim) == 4, sorted(usage)      # count<records>, count<no records>, scan, scatter
+    for k, v in slim.items():
+        assert v["VGPRs"] <= 128 and v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
+        assert v["LDS Size [bytes/block]"] <= 24 * 1024, (k, v)
